@@ -1,0 +1,176 @@
+/*
+ * vdb.h — C ABI of the MI355X-native exact cosine top-k engine (libvdb_hip.so).
+ *
+ * The reference (billenewman4/VectorDB, a pure-Python project) has no FFI of
+ * its own: its hot path leaves the repository through the chromadb Python
+ * object boundary.  Each entry point below therefore cites the reference
+ * *Python call site* whose work it replaces (paths relative to the reference
+ * checkout).  The Python host layer (vectordb_amd/) binds these symbols with
+ * ctypes; INTEGRATION.md shows the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C, opaque handle, every function returns 0 on success and a
+ *     negative vdb_status on failure; vdb_last_error() gives the message.
+ *   - caller allocates every output buffer; no callbacks; no exceptions.
+ *   - one host thread per handle at a time; different handles may be driven
+ *     from different threads.
+ *   - "host" pointers are ordinary CPU memory, "dev" pointers are device
+ *     memory on the handle's GPU (e.g. tensor.data_ptr()).
+ *   - row index = insertion order (0-based) + row_offset (shard offset).
+ *   - scores are cosine similarities of L2-normalised vectors; distances are
+ *     1 - cosine (fp32), ascending; ties are broken by ascending row index.
+ */
+#ifndef VDB_H
+#define VDB_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vdb vdb_t;
+
+enum vdb_status {
+  VDB_OK = 0,
+  VDB_ERR_ARG = -1,      /* invalid argument                        */
+  VDB_ERR_DEVICE = -2,   /* HIP runtime error / no GPU              */
+  VDB_ERR_MEMORY = -3,   /* allocation failed                       */
+  VDB_ERR_IO = -4,       /* save/load failure                       */
+  VDB_ERR_STATE = -5     /* call not valid in the handle's state    */
+};
+
+enum vdb_dtype { VDB_F32 = 0, VDB_BF16 = 1 };
+
+#define VDB_MAX_K 1024 /* largest k (or rerank k') one call may ask for */
+
+/* Counter-based synthetic row generator: identical bits on
+ * host (oracle) and device, so 150 GB corpora never cross PCIe.
+ *   kind 0  isotropic : x = u(seed,row,col), u uniform in [-1,1)
+ *   kind 1  clustered : x = u(seed^C, row % n_clusters, col) + noise*u(seed,row,col)
+ *   kind 2  query     : x = base_row(src) + noise*u(seed,row,col), where
+ *                       src = hash(seed,row) % base_n and base_row is the raw
+ *                       (un-normalised) row `src` of the corpus described by
+ *                       base_seed/base_kind/base_n_clusters/base_noise. */
+typedef struct vdb_synth_spec {
+  uint64_t seed;
+  int32_t kind;
+  int32_t n_clusters;
+  float noise;
+  int32_t base_kind;
+  uint64_t base_seed;
+  int64_t base_n;
+  int32_t base_n_clusters;
+  float base_noise;
+} vdb_synth_spec;
+
+/* ---- lifecycle --------------------------------------------------------- */
+
+/* Replaces chromadb.PersistentClient(...).get_or_create_collection(name,
+ * metadata={"hnsw:space":"cosine"}) as the owner of the vector segment
+ * (src/vectordb.py:149,156-160).  dtype: storage of the scanned copy.
+ * keep_f32_for_rerank: with VDB_BF16, also keep fp32 rows for the rerank. */
+int vdb_create(vdb_t** out, int dim, int dtype, int keep_f32_for_rerank, int device_id);
+
+/* Replaces client.delete_collection(name) for the vector segment
+ * (src/vectordb.py:180). */
+void vdb_destroy(vdb_t* h);
+
+/* Message of the last failing call on this handle (owned by the library).
+ * With h == NULL: the message of the last failing vdb_create/vdb_load. */
+const char* vdb_last_error(vdb_t* h);
+
+/* Pre-size the store for n_rows rows (avoids regrowth copies).  No reference
+ * counterpart (hnswlib's max_elements resize is internal to chromadb). */
+int vdb_reserve(vdb_t* h, int64_t n_rows);
+
+/* Global index of this shard's row 0 (multi-GPU row sharding). */
+int vdb_set_row_offset(vdb_t* h, int64_t row_offset);
+
+/* ---- add -------------------------------------------- */
+
+/* Replaces collection.add(embeddings=...) (src/vectordb.py:215-219): append n
+ * rows (host, row-major n x dim fp32).  Rows are L2-normalised on the device
+ * (cosine space) and stored fp32 and/or bf16. */
+int vdb_add(vdb_t* h, const float* rows_host, int64_t n);
+
+/* Same, rows already resident in device memory (embedder output, generator). */
+int vdb_add_dev(vdb_t* h, const float* rows_dev, int64_t n);
+
+/* Replaces collection.count() (tests/test_vectordb.py:101). */
+int vdb_count(vdb_t* h, int64_t* n);
+
+/* ---- query --------------------------------- */
+
+/* Replaces collection.query(query_embeddings=, n_results=k)
+ * (src/vectordb.py:259-264; analysis/bidirectional_similarity.py:110-114;
+ * analysis/run_bidirectional_test.py:139-143;
+ * analysis/generate_best_usda_matches.py:196-200) and the top-k selection
+ * inside chroma-hnswlib.  queries: host, b x dim fp32 (not required to be
+ * normalised).  rerank_kprime: 0 = no rerank; otherwise (bf16 store with fp32
+ * copy) the scan keeps k' >= k candidates that are re-scored in fp32
+ * (the GPU analogue of src/vectordb.py:282-314).  Outputs: b x k, padded with
+ * idx -1 / dist +inf when fewer than k rows exist. */
+int vdb_search(vdb_t* h, const float* queries_host, int b, int k, int rerank_kprime,
+               int64_t* out_idx_host, float* out_dist_host);
+
+/* Same with device-resident queries and outputs, asynchronous on `stream`
+ * (a hipStream_t; NULL = the handle's own stream).  The caller synchronises. */
+int vdb_search_dev(vdb_t* h, const float* queries_dev, int b, int k, int rerank_kprime,
+                   int64_t* out_idx_dev, float* out_dist_dev, void* stream);
+
+/* Multi-GPU merge (new in the build): after an all-gather of the
+ * per-shard results, cand_* hold g lists per query laid out [g][b][k]
+ * (ascending distance, idx -1 = empty); shard s starts at element
+ * s*dist_shard_stride / s*idx_shard_stride (0 = dense, b*k), so one packed
+ * all-gather buffer can be merged in place.  Writes the b x k global top-k. */
+int vdb_merge_topk_dev(vdb_t* h, const float* cand_dist_dev, int64_t dist_shard_stride,
+                       const int64_t* cand_idx_dev, int64_t idx_shard_stride, int g, int b, int k,
+                       int64_t* out_idx_dev, float* out_dist_dev, void* stream);
+
+/* All-pairs self-join over stored rows [q_row0, q_row0+q_n) as queries
+ * (the loop of analysis/bidirectional_similarity.py:246-271, which issues one
+ * query per product).  exclude_self drops the query's own row
+ * (bidirectional_similarity.py:161 skips self matches).  Outputs host,
+ * q_n x k. */
+int vdb_selfjoin(vdb_t* h, int64_t q_row0, int64_t q_n, int k, int exclude_self,
+                 int rerank_kprime, int64_t* out_idx_host, float* out_dist_host);
+
+/* Replaces collection.get(ids=, include=["embeddings"]) and the
+ * include=["embeddings"] part of query (src/vectordb.py:262,270;
+ * analysis/generate_best_usda_matches.py:185-188): copy the stored
+ * (normalised, fp32) rows with the given *local* indices to host. */
+int vdb_fetch(vdb_t* h, const int64_t* idx_host, int64_t n, float* out_rows_host);
+
+/* ---- persistence ------------------------------------ */
+
+/* Replace the PersistentClient directory (src/config.py:43,
+ * src/vectordb.py:149): flat file `<dir>/vectors.vdb`. */
+int vdb_save(vdb_t* h, const char* dir);
+int vdb_load(vdb_t** out, const char* dir, int dtype, int keep_f32_for_rerank, int device_id);
+
+/* ---- measurement ------------------------------------------------------- */
+
+/* hipEvent timing of the last search on this handle: scan kernel(s) time,
+ * merge+rerank time, and the algorithmic bytes the scan streamed
+ * (n * dim * sizeof(T) per corpus pass).  Synchronises the handle's events. */
+int vdb_last_timing(vdb_t* h, float* scan_ms, float* merge_ms, double* bytes_streamed);
+
+/* Tuning knobs: "scan_blocks_per_cu", "scan_nt_loads", "batch_mfma_min_b".
+ * Unknown names return VDB_ERR_ARG. */
+int vdb_set_option(vdb_t* h, const char* name, int64_t value);
+
+/* ---- synthetic data (bench/test utility; no reference counterpart) ----- */
+
+/* Write raw (un-normalised) synthetic rows [row0,row0+n) into out_dev
+ * (n x dim fp32, device memory on the handle's GPU). */
+int vdb_synth_rows_dev(vdb_t* h, float* out_dev, int64_t row0, int64_t n,
+                       const vdb_synth_spec* spec, void* stream);
+
+/* Generate and append rows [row0,row0+n) chunk by chunk on the device. */
+int vdb_add_synth(vdb_t* h, int64_t row0, int64_t n, const vdb_synth_spec* spec);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VDB_H */

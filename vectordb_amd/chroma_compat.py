@@ -1,0 +1,395 @@
+"""Chroma-shaped client/collection over the MI355X exact cosine engine.
+
+Reproduces exactly the slice of the chromadb API the reference touches
+("Complete Chroma API surface"):
+
+  chromadb.PersistentClient(path=)                      src/vectordb.py:149
+  client.get_or_create_collection(name=, embedding_function=,
+        metadata={"hnsw:space": "cosine"})              src/vectordb.py:156,183
+  client.delete_collection(name=)                       src/vectordb.py:180
+  client.get_collection(name) / collection.count()      tests/test_vectordb.py:98,101
+  collection.add(embeddings=, metadatas=, ids=)         src/vectordb.py:215
+  collection.query(query_embeddings=, n_results=, include=, where=)
+        src/vectordb.py:259; analysis/bidirectional_similarity.py:110;
+        analysis/run_bidirectional_test.py:139; analysis/generate_best_usda_matches.py:196
+  collection.get(ids=, include=)                        analysis/generate_best_usda_matches.py:185
+
+The vector segment (chromadb's HNSW index) is a FlatIndex on the GPU; ids,
+metadatas and the embeddings *as added* stay on the host, the role sqlite plays
+inside chromadb.  Search is exact, so results equal Chroma's only up to HNSW's
+approximation error.
+"""
+from __future__ import annotations
+
+import json
+import os
+import shutil
+from typing import Any, Dict, List, Optional, Sequence
+
+import numpy as np
+
+from .index import FlatIndex
+
+_VALID_INCLUDE = {"embeddings", "metadatas", "documents", "distances", "uris", "data"}
+_DEFAULT_QUERY_INCLUDE = ("metadatas", "documents", "distances")
+_DEFAULT_GET_INCLUDE = ("metadatas", "documents")
+
+
+def _match_where(meta: Optional[dict], where: dict) -> bool:
+    """Chroma metadata filter: {"k": v}, {"k": {"$eq"|"$ne"|"$in"|"$nin"|"$gt"|"$gte"|"$lt"|"$lte": v}},
+    {"$and": [...]}, {"$or": [...]}."""
+    meta = meta or {}
+    for key, cond in where.items():
+        if key == "$and":
+            if not all(_match_where(meta, w) for w in cond):
+                return False
+        elif key == "$or":
+            if not any(_match_where(meta, w) for w in cond):
+                return False
+        elif isinstance(cond, dict):
+            if key not in meta:
+                return False
+            v = meta[key]
+            for op, ref in cond.items():
+                ok = {"$eq": lambda: v == ref, "$ne": lambda: v != ref, "$in": lambda: v in ref,
+                      "$nin": lambda: v not in ref, "$gt": lambda: v > ref, "$gte": lambda: v >= ref,
+                      "$lt": lambda: v < ref, "$lte": lambda: v <= ref}.get(op)
+                if ok is None:
+                    raise ValueError(f"Expected where operator to be one of $eq,$ne,$in,$nin,$gt,$gte,$lt,$lte; got {op}")
+                if not ok():
+                    return False
+        else:
+            if meta.get(key, object()) != cond:
+                return False
+    return True
+
+
+class Collection:
+    """Cosine-space collection.  ``embeddings_as='numpy'`` mirrors recent chromadb
+    (query: list of 2-D arrays; get: one 2-D array), which is what the reference's
+    saved output was produced with (analysis_results/best_usda_matches.csv:2 holds
+    the list-valued product_id that only that return shape produces); 'list' gives
+    nested Python lists as in chromadb 0.4.x."""
+
+    def __init__(self, name: str, path: Optional[str], embedding_function=None, metadata: Optional[dict] = None,
+                 *, dtype: str = "f32", device: int = 0, rerank_kprime: Optional[int] = None, lib=None,
+                 embeddings_as: str = "numpy", auto_persist: bool = True):
+        metadata = dict(metadata or {})
+        space = metadata.get("hnsw:space", "l2")
+        if space != "cosine":
+            raise ValueError(f"only the cosine space is implemented (metadata={{'hnsw:space': 'cosine'}}); got {space!r}")
+        self.name = name
+        self.metadata = metadata
+        self._path = path
+        self._embedding_function = embedding_function
+        self._dtype = dtype
+        self._device = device
+        self._lib = lib
+        self._rerank_kprime = rerank_kprime
+        self._embeddings_as = embeddings_as
+        self._auto_persist = auto_persist and path is not None
+        self._ids: List[str] = []
+        self._id_to_row: Dict[str, int] = {}
+        self._metadatas: List[Optional[dict]] = []
+        self._documents: List[Optional[str]] = []
+        self._raw: List[np.ndarray] = []          # chunks of embeddings as added (fp32)
+        self._raw_cat: Optional[np.ndarray] = None
+        self._index: Optional[FlatIndex] = None
+        self._dim: Optional[int] = None
+
+    # -- internals ---------------------------------------------------------
+    def _ensure_index(self, dim: int) -> FlatIndex:
+        if self._index is None:
+            self._dim = dim
+            self._index = FlatIndex(dim, self._dtype, True, self._device, lib=self._lib)
+        elif dim != self._dim:
+            raise ValueError(f"Embedding dimension {dim} does not match collection dimensionality {self._dim}")
+        return self._index
+
+    def _raw_matrix(self) -> np.ndarray:
+        if self._raw_cat is None or len(self._raw) > 1:
+            self._raw_cat = (np.concatenate(self._raw, axis=0) if self._raw
+                             else np.zeros((0, self._dim or 0), np.float32))
+            self._raw = [self._raw_cat]
+        return self._raw_cat
+
+    def _kprime(self, k: int) -> int:
+        if self._dtype != "bf16":
+            return 0
+        kp = self._rerank_kprime if self._rerank_kprime is not None else max(4 * k, 32)
+        return int(min(max(kp, k), 1024))
+
+    def _embed(self, texts: Sequence[str]) -> np.ndarray:
+        if self._embedding_function is None:
+            raise ValueError("You must provide embeddings (no embedding_function is set on this collection)")
+        return np.asarray(self._embedding_function(list(texts)), dtype=np.float32)
+
+    def _format_embeddings(self, mat: np.ndarray):
+        return mat if self._embeddings_as == "numpy" else mat.tolist()
+
+    # -- chroma API --------------------------------------------------------
+    def count(self) -> int:
+        return len(self._ids)
+
+    def add(self, ids, embeddings=None, metadatas=None, documents=None) -> None:
+        ids = [ids] if isinstance(ids, str) else list(ids)
+        n = len(ids)
+        if len(set(ids)) != n:
+            dup = sorted({i for i in ids if ids.count(i) > 1})[:5]
+            raise ValueError(f"Expected IDs to be unique, found duplicates of: {', '.join(dup)}")
+        if embeddings is None:
+            if documents is None:
+                raise ValueError("You must provide either embeddings or documents")
+            embeddings = self._embed([documents] if isinstance(documents, str) else documents)
+        emb = np.asarray(embeddings, dtype=np.float32)
+        if emb.ndim == 1:
+            emb = emb.reshape(1, -1)
+        if emb.ndim != 2 or emb.shape[0] != n:
+            raise ValueError(f"Number of embeddings {emb.shape[0] if emb.ndim == 2 else '?'} must match number of ids {n}")
+        for name, seq in (("metadatas", metadatas), ("documents", documents)):
+            if seq is not None and not isinstance(seq, (str, dict)) and len(seq) != n:
+                raise ValueError(f"Number of {name} {len(seq)} must match number of ids {n}")
+        if n == 0:
+            return
+        if isinstance(metadatas, dict):
+            metadatas = [metadatas]
+        if isinstance(documents, str):
+            documents = [documents]
+        # chromadb ignores ids that already exist on add()
+        keep = [j for j, i in enumerate(ids) if i not in self._id_to_row]
+        if not keep:
+            return
+        if len(keep) != n:
+            emb = emb[keep]
+        index = self._ensure_index(emb.shape[1])
+        index.add(emb)
+        base = len(self._ids)
+        for off, j in enumerate(keep):
+            self._id_to_row[ids[j]] = base + off
+            self._ids.append(ids[j])
+            self._metadatas.append(dict(metadatas[j]) if metadatas is not None and metadatas[j] is not None else None)
+            self._documents.append(documents[j] if documents is not None else None)
+        self._raw.append(np.ascontiguousarray(emb))
+        self._raw_cat = None
+        if self._auto_persist:
+            self.persist()
+
+    def query(self, query_embeddings=None, query_texts=None, n_results: int = 10, where: Optional[dict] = None,
+              where_document: Optional[dict] = None, include: Sequence[str] = _DEFAULT_QUERY_INCLUDE) -> Dict[str, Any]:
+        if where_document:
+            raise NotImplementedError("where_document filtering is not implemented")
+        include = list(include)
+        bad = [i for i in include if i not in _VALID_INCLUDE]
+        if bad:
+            raise ValueError(f"Expected include item to be one of {sorted(_VALID_INCLUDE)}, got {bad[0]}")
+        if query_embeddings is None:
+            if query_texts is None:
+                raise ValueError("You must provide one of query_embeddings or query_texts")
+            query_embeddings = self._embed([query_texts] if isinstance(query_texts, str) else query_texts)
+        if not isinstance(n_results, int) or isinstance(n_results, bool) or n_results <= 0:
+            raise ValueError(f"Number of requested results {n_results} must be a positive integer")
+        q = np.asarray(query_embeddings, dtype=np.float32)
+        if q.ndim == 1:
+            q = q.reshape(1, -1)
+        b = q.shape[0]
+        total = self.count()
+        if total and q.shape[1] != self._dim:
+            raise ValueError(f"Embedding dimension {q.shape[1]} does not match collection dimensionality {self._dim}")
+
+        rows: List[np.ndarray]
+        dists: List[np.ndarray]
+        if total == 0:
+            rows = [np.zeros(0, np.int64) for _ in range(b)]
+            dists = [np.zeros(0, np.float32) for _ in range(b)]
+        elif where:
+            rows, dists = self._query_filtered(q, n_results, where)
+        else:
+            k = min(n_results, total)           # chromadb clamps n_results to the collection size
+            idx, dist = self._index.search(q, k, self._kprime(k))
+            rows = [idx[i][idx[i] >= 0] for i in range(b)]
+            dists = [dist[i][: len(rows[i])] for i in range(b)]
+
+        out: Dict[str, Any] = {"ids": [[self._ids[r] for r in rr] for rr in rows],
+                               "distances": None, "metadatas": None, "embeddings": None, "documents": None,
+                               "uris": None, "data": None, "included": include}
+        if "distances" in include:
+            out["distances"] = [[float(d) for d in dd] for dd in dists]
+        if "metadatas" in include:
+            out["metadatas"] = [[self._metadatas[r] for r in rr] for rr in rows]
+        if "documents" in include:
+            out["documents"] = [[self._documents[r] for r in rr] for rr in rows]
+        if "embeddings" in include:
+            raw = self._raw_matrix()
+            out["embeddings"] = [self._format_embeddings(raw[rr]) for rr in rows]
+        return out
+
+    def _query_filtered(self, q: np.ndarray, n_results: int, where: dict):
+        """Metadata pre-filter (exact): the matching rows are searched as a temporary
+        shard.  No reference caller passes `where` (src/vectordb.py:230 default None)."""
+        allowed = np.array([r for r, m in enumerate(self._metadatas) if _match_where(m, where)], dtype=np.int64)
+        b = q.shape[0]
+        if allowed.size == 0:
+            return [np.zeros(0, np.int64)] * b, [np.zeros(0, np.float32)] * b
+        sub = FlatIndex(self._dim, self._dtype, True, self._device, lib=self._lib)
+        try:
+            sub.add(self._raw_matrix()[allowed])
+            k = min(n_results, allowed.size)
+            idx, dist = sub.search(q, k, self._kprime(k))
+        finally:
+            sub.close()
+        rows = [allowed[idx[i][idx[i] >= 0]] for i in range(b)]
+        return rows, [dist[i][: len(rows[i])] for i in range(b)]
+
+    def get(self, ids=None, where: Optional[dict] = None, limit: Optional[int] = None, offset: Optional[int] = None,
+            include: Sequence[str] = _DEFAULT_GET_INCLUDE) -> Dict[str, Any]:
+        include = list(include)
+        if ids is None:
+            rows = list(range(self.count()))
+        else:
+            ids = [ids] if isinstance(ids, str) else list(ids)
+            rows = [self._id_to_row[i] for i in ids if i in self._id_to_row]  # unknown ids are dropped
+        if where:
+            rows = [r for r in rows if _match_where(self._metadatas[r], where)]
+        if offset:
+            rows = rows[offset:]
+        if limit is not None:
+            rows = rows[:limit]
+        out: Dict[str, Any] = {"ids": [self._ids[r] for r in rows], "embeddings": None, "metadatas": None,
+                               "documents": None, "uris": None, "data": None, "included": include}
+        if "metadatas" in include:
+            out["metadatas"] = [self._metadatas[r] for r in rows]
+        if "documents" in include:
+            out["documents"] = [self._documents[r] for r in rows]
+        if "embeddings" in include:
+            raw = self._raw_matrix()
+            out["embeddings"] = self._format_embeddings(raw[np.asarray(rows, dtype=np.int64)] if rows
+                                                        else np.zeros((0, self._dim or 0), np.float32))
+        return out
+
+    def peek(self, limit: int = 10) -> Dict[str, Any]:
+        return self.get(limit=limit, include=["embeddings", "metadatas", "documents"])
+
+    # -- persistence (flat store) ----------------------
+    def _dir(self) -> str:
+        return os.path.join(self._path, self.name)
+
+    def persist(self) -> None:
+        if self._path is None:
+            return
+        d = self._dir()
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "collection.json"), "w") as f:
+            json.dump({"name": self.name, "metadata": self.metadata, "dim": self._dim, "count": self.count()}, f)
+        with open(os.path.join(d, "records.jsonl"), "w") as f:
+            for i, m, doc in zip(self._ids, self._metadatas, self._documents):
+                f.write(json.dumps({"id": i, "metadata": m, "document": doc}) + "\n")
+        if self._index is not None:
+            np.save(os.path.join(d, "embeddings.npy"), self._raw_matrix(), allow_pickle=False)
+            self._index.save(d)
+
+    def _load(self) -> None:
+        d = self._dir()
+        with open(os.path.join(d, "collection.json")) as f:
+            info = json.load(f)
+        self.metadata = info.get("metadata") or self.metadata
+        self._dim = info.get("dim")
+        with open(os.path.join(d, "records.jsonl")) as f:
+            for line in f:
+                rec = json.loads(line)
+                self._id_to_row[rec["id"]] = len(self._ids)
+                self._ids.append(rec["id"])
+                self._metadatas.append(rec["metadata"])
+                self._documents.append(rec["document"])
+        if self._dim and os.path.exists(os.path.join(d, "vectors.vdb")):
+            self._raw = [np.load(os.path.join(d, "embeddings.npy"), allow_pickle=False)]
+            self._index = FlatIndex.load(d, self._dtype, True, self._device, lib=self._lib)
+            if self._index.count() != len(self._ids):
+                raise RuntimeError(f"corrupt collection {self.name}: {self._index.count()} vectors, {len(self._ids)} records")
+
+    def _close(self) -> None:
+        if self._index is not None:
+            self._index.close()
+            self._index = None
+
+
+class PersistentClient:
+    """Drop-in for ``chromadb.PersistentClient`` (src/vectordb.py:149).  Extra
+    keyword arguments select the engine configuration and are not part of Chroma."""
+
+    def __init__(self, path: str = "./chroma", *, dtype: str = "f32", device: int = 0,
+                 rerank_kprime: Optional[int] = None, lib=None, embeddings_as: str = "numpy",
+                 auto_persist: bool = True):
+        self._path = str(path)
+        os.makedirs(self._path, exist_ok=True)
+        self._opts = dict(dtype=dtype, device=device, rerank_kprime=rerank_kprime, lib=lib,
+                          embeddings_as=embeddings_as, auto_persist=auto_persist)
+        self._open: Dict[str, Collection] = {}
+
+    def _exists(self, name: str) -> bool:
+        return name in self._open or os.path.exists(os.path.join(self._path, name, "collection.json"))
+
+    def list_collections(self) -> List[str]:
+        names = set(self._open)
+        for n in os.listdir(self._path):
+            if os.path.exists(os.path.join(self._path, n, "collection.json")):
+                names.add(n)
+        return sorted(names)
+
+    def get_collection(self, name: str, embedding_function=None) -> Collection:
+        if name in self._open:
+            return self._open[name]
+        if not self._exists(name):
+            raise ValueError(f"Collection {name} does not exist.")
+        col = Collection(name, self._path, embedding_function, {"hnsw:space": "cosine"}, **self._opts)
+        col._load()
+        self._open[name] = col
+        return col
+
+    def create_collection(self, name: str, embedding_function=None, metadata: Optional[dict] = None,
+                          get_or_create: bool = False) -> Collection:
+        if self._exists(name):
+            if get_or_create:
+                col = self.get_collection(name, embedding_function)
+                if embedding_function is not None:
+                    col._embedding_function = embedding_function
+                return col
+            raise ValueError(f"Collection {name} already exists")
+        col = Collection(name, self._path, embedding_function, metadata, **self._opts)
+        self._open[name] = col
+        if col._auto_persist:
+            col.persist()
+        return col
+
+    def get_or_create_collection(self, name: str, embedding_function=None, metadata: Optional[dict] = None) -> Collection:
+        return self.create_collection(name, embedding_function, metadata, get_or_create=True)
+
+    def delete_collection(self, name: str) -> None:
+        if not self._exists(name):
+            raise ValueError(f"Collection {name} does not exist.")
+        col = self._open.pop(name, None)
+        if col is not None:
+            col._close()
+        shutil.rmtree(os.path.join(self._path, name), ignore_errors=True)
+
+
+class EphemeralClient(PersistentClient):
+    """In-memory variant (no files)."""
+
+    def __init__(self, **kw):
+        kw.pop("auto_persist", None)
+        self._path = None
+        self._opts = dict(dtype=kw.get("dtype", "f32"), device=kw.get("device", 0),
+                          rerank_kprime=kw.get("rerank_kprime"), lib=kw.get("lib"),
+                          embeddings_as=kw.get("embeddings_as", "numpy"), auto_persist=False)
+        self._open = {}
+
+    def _exists(self, name: str) -> bool:
+        return name in self._open
+
+    def list_collections(self) -> List[str]:
+        return sorted(self._open)
+
+    def delete_collection(self, name: str) -> None:
+        if name not in self._open:
+            raise ValueError(f"Collection {name} does not exist.")
+        self._open.pop(name)._close()

@@ -1,0 +1,221 @@
+// scan_gemv.h — the HBM-bound hot kernel: stream the corpus once, score every
+// row against QB queries held in registers, keep a fused per-wave top-k.
+// Replaces chroma-hnswlib's searchKnn behind collection.query
+// (reference: src/vectordb.py:259-264).  The score matrix is never written.
+//
+// Data layout: rows are row-major, DIM elements, 16-byte aligned, L2-normalised.
+// A wave walks the corpus as a flat array of 16-byte chunks: one
+// global_load_dwordx4 per lane = 1 KiB per wave-instruction, fully coalesced.
+// L loads cover R whole rows (L*64 chunks = R*CPR chunks); U such groups are
+// issued back to back (12 KiB in flight per wave at DIM=768).
+#pragma once
+#include "wave_prims.h"
+
+namespace vdbk {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kScanThreads = 256;
+constexpr int kScanWaves = kScanThreads / 64;
+
+__host__ __device__ constexpr int cgcd(int a, int b) { return b == 0 ? a : cgcd(b, a % b); }
+
+template <typename T> struct ElemTraits;
+template <> struct ElemTraits<float> { static constexpr int kPerChunk = 4; };
+struct bf16_t { uint16_t bits; };
+template <> struct ElemTraits<bf16_t> { static constexpr int kPerChunk = 8; };
+
+template <bool NT>
+__device__ __forceinline__ u32x4 load_chunk(const u32x4* p) {
+  if constexpr (NT) return __builtin_nontemporal_load(p);
+  else return *p;
+}
+
+// dot of one 16-byte chunk with the matching query slice
+template <typename T>
+__device__ __forceinline__ float chunk_dot(const u32x4 v, const float* q);
+template <>
+__device__ __forceinline__ float chunk_dot<float>(const u32x4 v, const float* q) {
+  float a = __uint_as_float(v.x) * q[0];
+  a = fmaf(__uint_as_float(v.y), q[1], a);
+  a = fmaf(__uint_as_float(v.z), q[2], a);
+  a = fmaf(__uint_as_float(v.w), q[3], a);
+  return a;
+}
+template <>
+__device__ __forceinline__ float chunk_dot<bf16_t>(const u32x4 v, const float* q) {
+  float a = __uint_as_float(v.x << 16) * q[0];
+  a = fmaf(__uint_as_float(v.x & 0xffff0000u), q[1], a);
+  a = fmaf(__uint_as_float(v.y << 16), q[2], a);
+  a = fmaf(__uint_as_float(v.y & 0xffff0000u), q[3], a);
+  a = fmaf(__uint_as_float(v.z << 16), q[4], a);
+  a = fmaf(__uint_as_float(v.z & 0xffff0000u), q[5], a);
+  a = fmaf(__uint_as_float(v.w << 16), q[6], a);
+  a = fmaf(__uint_as_float(v.w & 0xffff0000u), q[7], a);
+  return a;
+}
+
+// Block-level merge of the per-wave lists + write of one partial list per query:
+// out layout [q][part][kk].
+template <int QB, int E>
+__device__ __forceinline__ void block_merge_store(WaveTopK<E> (&tk)[QB], int kk, float* __restrict__ part_s,
+                                                  int* __restrict__ part_i, int n_parts, int part) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  float* ls = reinterpret_cast<float*>(smem_raw);          // [waves][QB][kk]
+  int* li = reinterpret_cast<int*>(ls + kScanWaves * QB * kk);
+  const int w = threadIdx.x >> 6;
+  const int lane = lane_id();
+#pragma unroll
+  for (int q = 0; q < QB; ++q) tk[q].store(ls + (w * QB + q) * kk, li + (w * QB + q) * kk);
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < QB; ++q) {
+    if ((q % kScanWaves) == w) {  // wave w finishes query q (wave-uniform)
+      for (int ow = 0; ow < kScanWaves; ++ow) {
+        if (ow == w) continue;
+        const float* os = ls + (ow * QB + q) * kk;
+        const int* oi = li + (ow * QB + q) * kk;
+        for (int base = 0; base < kk; base += 64) {
+          const int p = base + lane;
+          const bool valid = p < kk;
+          const float cs = valid ? os[p] : -INFINITY;
+          const int ci = valid ? oi[p] : kIdxSentinel;
+          tk[q].push_lanes(cs, ci, valid);
+        }
+      }
+      tk[q].store(part_s + ((size_t)q * n_parts + part) * kk, part_i + ((size_t)q * n_parts + part) * kk);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Fast path: compile-time DIM (768, 384), QB queries per corpus pass.
+//   qn      : QB x DIM normalised fp32 queries (device)
+//   self0   : >=0 -> query q must not return row self0+q (self-join)
+//   part_*  : [QB][gridDim.x][kk] partial lists
+// ---------------------------------------------------------------------------
+template <typename T, int DIM, int QB, int E, bool NT>
+__global__ __launch_bounds__(kScanThreads) void scan_topk_kernel(const void* __restrict__ rows_v, int n_rows,
+                                                                  const float* __restrict__ qn, int kk,
+                                                                  int self0, float* __restrict__ part_s,
+                                                                  int* __restrict__ part_i) {
+  constexpr int EPC = ElemTraits<T>::kPerChunk;   // elements per 16-byte chunk
+  constexpr int CPR = DIM / EPC;                  // chunks per row
+  constexpr int G = cgcd(CPR, 64);
+  constexpr int L = CPR / G;                      // wave-loads per group
+  constexpr int R = 64 / G;                       // rows per group
+  constexpr int U = (L >= 12) ? 1 : (12 / L);     // groups per tile
+  constexpr int RPT = U * R;                      // rows per tile
+  static_assert(DIM % EPC == 0, "row must be a whole number of 16-byte chunks");
+
+  const u32x4* __restrict__ rows = reinterpret_cast<const u32x4*>(rows_v);
+  const int lane = lane_id();
+  const int w = threadIdx.x >> 6;
+
+  // per-lane query slices: load j of a group covers chunk (j*64+lane) % CPR of its row
+  float qreg[QB][L][EPC];
+#pragma unroll
+  for (int q = 0; q < QB; ++q)
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+      const int cc = (j * 64 + lane) % CPR;
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) qreg[q][j][e] = qn[q * DIM + cc * EPC + e];
+    }
+
+  WaveTopK<E> tk[QB];
+#pragma unroll
+  for (int q = 0; q < QB; ++q) tk[q].init(kk);
+
+  const long long n_tiles = ((long long)n_rows + RPT - 1) / RPT;
+  const long long total_chunks = (long long)n_rows * CPR;
+  const long long gw = (long long)blockIdx.x * kScanWaves + w;
+  const long long nw = (long long)gridDim.x * kScanWaves;
+
+  for (long long tile = gw; tile < n_tiles; tile += nw) {
+    const long long c0 = tile * (long long)(RPT * CPR) + lane;
+    u32x4 v[U * L];
+    if ((tile + 1) * RPT <= (long long)n_rows) {
+#pragma unroll
+      for (int t = 0; t < U * L; ++t) v[t] = load_chunk<NT>(rows + c0 + t * 64);
+    } else {
+#pragma unroll
+      for (int t = 0; t < U * L; ++t) {
+        const long long c = c0 + t * 64;
+        v[t] = (c < total_chunks) ? load_chunk<NT>(rows + c) : u32x4{0u, 0u, 0u, 0u};
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int q = 0; q < QB; ++q) {
+        float p[L];
+#pragma unroll
+        for (int j = 0; j < L; ++j) p[j] = chunk_dot<T>(v[u * L + j], qreg[q][j]);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          float acc = 0.f;
+#pragma unroll
+          for (int j = 0; j < L; ++j) {
+            // lanes of load j that belong to row r of the group: [lo, hi)
+            constexpr int dummy = 0; (void)dummy;
+            const int lo = r * CPR - j * 64, hi = lo + CPR;
+            if (lo <= 0 && hi >= 64) acc += p[j];
+            else if (hi <= 0 || lo >= 64) { /* no lane */ }
+            else acc += (lane >= lo && lane < hi) ? p[j] : 0.f;
+          }
+          const float tot = wave_sum(acc);
+          const long long row = tile * RPT + u * R + r;
+          if (row < (long long)n_rows) {
+            const int ri = (int)row;
+            const bool self = (self0 >= 0) && (ri == self0 + q);
+            if (!self && tk[q].accepts(tot, ri)) tk[q].insert(tot, ri);
+          }
+        }
+      }
+    }
+  }
+  block_merge_store<QB, E>(tk, kk, part_s, part_i, gridDim.x, blockIdx.x);
+}
+
+// ---------------------------------------------------------------------------
+// Generic path: any (padded) row length ld (multiple of the chunk size), one
+// row per wave step, query staged in LDS.  One query per pass.
+// ---------------------------------------------------------------------------
+template <typename T, int E, bool NT>
+__global__ __launch_bounds__(kScanThreads) void scan_topk_generic_kernel(const void* __restrict__ rows_v, int n_rows,
+                                                                         int ld, const float* __restrict__ qn,
+                                                                         int kk, int self_row,
+                                                                         float* __restrict__ part_s,
+                                                                         int* __restrict__ part_i) {
+  constexpr int EPC = ElemTraits<T>::kPerChunk;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  // query lives after the merge area: [waves*kk floats][waves*kk ints][ld floats]
+  float* qs = reinterpret_cast<float*>(smem_raw) + 2 * kScanWaves * kk;
+  for (int c = threadIdx.x; c < ld; c += blockDim.x) qs[c] = qn[c];
+  __syncthreads();
+
+  const u32x4* __restrict__ rows = reinterpret_cast<const u32x4*>(rows_v);
+  const int cpr = ld / EPC;
+  const int lane = lane_id();
+  const int w = threadIdx.x >> 6;
+  WaveTopK<E> tk[1];
+  tk[0].init(kk);
+  const long long gw = (long long)blockIdx.x * kScanWaves + w;
+  const long long nw = (long long)gridDim.x * kScanWaves;
+  for (long long row = gw; row < (long long)n_rows; row += nw) {
+    float acc = 0.f;
+    for (int c = lane; c < cpr; c += 64) {
+      const u32x4 v = load_chunk<NT>(rows + row * cpr + c);
+      acc += chunk_dot<T>(v, qs + c * EPC);
+    }
+    const float tot = wave_sum(acc);
+    const int ri = (int)row;
+    if (ri != self_row && tk[0].accepts(tot, ri)) tk[0].insert(tot, ri);
+  }
+  __syncthreads();  // query reads done before the merge area is reused (disjoint, but keep order explicit)
+  block_merge_store<1, E>(tk, kk, part_s, part_i, gridDim.x, blockIdx.x);
+}
+
+}  // namespace vdbk

@@ -1,0 +1,223 @@
+// select.h — small kernels after the scan: hierarchical merge of partial
+// top-k lists, fp32 rerank (GPU analogue of src/vectordb.py:282-314), final
+// ranking / output conversion, and the cross-shard merge used after the RCCL
+// all-gather.
+#pragma once
+#include "scan_gemv.h"
+
+namespace vdbk {
+
+constexpr int kMergeThreads = 256;
+constexpr int kMergeWaves = kMergeThreads / 64;
+
+// Merge candidates [q][n_cand] (any order; sentinel entries allowed) into
+// gridDim.x lists of kk per query: out [q][gridDim.x][kk].
+template <int E>
+__global__ __launch_bounds__(kMergeThreads) void merge_lists_kernel(const float* __restrict__ in_s,
+                                                                    const int* __restrict__ in_i, int n_cand,
+                                                                    int cand_per_block, int kk,
+                                                                    float* __restrict__ out_s,
+                                                                    int* __restrict__ out_i) {
+  const int q = blockIdx.y;
+  const int w = threadIdx.x >> 6;
+  const int lane = lane_id();
+  const int start = blockIdx.x * cand_per_block;
+  const int end = min(n_cand, start + cand_per_block);
+  const float* cs_base = in_s + (size_t)q * n_cand;
+  const int* ci_base = in_i + (size_t)q * n_cand;
+  WaveTopK<E> tk[1];
+  tk[0].init(kk);
+  for (int base = start + w * 64; base < end; base += kMergeThreads) {
+    const int i = base + lane;
+    const bool valid = i < end;
+    const float cs = valid ? cs_base[i] : -INFINITY;
+    const int ci = valid ? ci_base[i] : kIdxSentinel;
+    tk[0].push_lanes(cs, ci, valid);
+  }
+  // reuse the scan's block merge: writes out[q_local=0][part][kk] relative to the query base
+  block_merge_store<1, E>(tk, kk, out_s + (size_t)q * gridDim.x * kk, out_i + (size_t)q * gridDim.x * kk,
+                          gridDim.x, blockIdx.x);
+}
+
+__device__ __forceinline__ bool dist_better(float d, long long i, float od, long long oi) {
+  return (d < od) || (d == od && i < oi);
+}
+
+// Final ranking of one query's m candidates (score, local idx) held in LDS:
+// order by (distance asc, index asc) — the same key the cross-shard merge uses,
+// so results do not depend on the number of shards.  Writes k outputs.
+__device__ __forceinline__ void rank_and_write(const float* ls, const int* li, int m, int k, long long row_offset,
+                                               long long* __restrict__ out_idx, float* __restrict__ out_dist) {
+  for (int t = threadIdx.x; t < k; t += blockDim.x) { out_idx[t] = -1; out_dist[t] = INFINITY; }
+  __syncthreads();
+  for (int t = threadIdx.x; t < m; t += blockDim.x) {
+    const int id = li[t];
+    const float sc = ls[t];
+    if (id == kIdxSentinel || !(sc == sc)) continue;
+    const float d = 1.0f - sc;
+    int rank = 0;
+    for (int j = 0; j < m; ++j) {
+      const int oj = li[j];
+      const float sj = ls[j];
+      if (oj == kIdxSentinel || !(sj == sj)) continue;
+      rank += dist_better(1.0f - sj, oj, d, id) ? 1 : 0;
+    }
+    if (rank < k) { out_idx[rank] = (long long)id + row_offset; out_dist[rank] = d; }
+  }
+}
+
+// No-rerank finish: merged [b][kk] -> outputs [b][k].  LDS: kk*(4+4) bytes.
+__global__ __launch_bounds__(256) void finalize_kernel(const float* __restrict__ m_s, const int* __restrict__ m_i,
+                                                       int kk, int k, long long row_offset,
+                                                       long long* __restrict__ out_idx,
+                                                       float* __restrict__ out_dist) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  float* ls = reinterpret_cast<float*>(smem_raw);
+  int* li = reinterpret_cast<int*>(ls + kk);
+  const int q = blockIdx.x;
+  for (int t = threadIdx.x; t < kk; t += blockDim.x) { ls[t] = m_s[(size_t)q * kk + t]; li[t] = m_i[(size_t)q * kk + t]; }
+  __syncthreads();
+  rank_and_write(ls, li, kk, k, row_offset, out_idx + (size_t)q * k, out_dist + (size_t)q * k);
+}
+
+// fp32 rerank: exact fp32 dot of the query with each of the kk candidate rows
+// (fp32 copy of the store), then final ranking.  One block per query.
+__global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ rows_f32, int ld,
+                                                     const float* __restrict__ qn, const int* __restrict__ m_i,
+                                                     int kk, int k, long long row_offset,
+                                                     long long* __restrict__ out_idx,
+                                                     float* __restrict__ out_dist) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  float* ls = reinterpret_cast<float*>(smem_raw);
+  int* li = reinterpret_cast<int*>(ls + kk);
+  const int q = blockIdx.x;
+  const int w = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+  const int lane = lane_id();
+  const f32x4* qv = reinterpret_cast<const f32x4*>(qn + (size_t)q * ld);
+  const int c4 = ld >> 2;
+  for (int c = w; c < kk; c += nwv) {
+    const int id = m_i[(size_t)q * kk + c];
+    float tot = -INFINITY;
+    if (id != kIdxSentinel) {  // wave-uniform
+      const f32x4* rv = reinterpret_cast<const f32x4*>(rows_f32 + (size_t)id * ld);
+      float acc = 0.f;
+      for (int j = lane; j < c4; j += 64) {
+        const f32x4 a = rv[j], b = qv[j];
+        acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc);
+        acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
+      }
+      tot = wave_sum(acc);
+    }
+    if (lane == 0) { ls[c] = tot; li[c] = id; }
+  }
+  __syncthreads();
+  rank_and_write(ls, li, kk, k, row_offset, out_idx + (size_t)q * k, out_dist + (size_t)q * k);
+}
+
+// Cross-shard merge after the all-gather: g sorted lists per query, layout
+// [g][b][k]; rank = own position + binary-searched counts in the other lists.
+__global__ __launch_bounds__(256) void merge_shards_kernel(const float* __restrict__ cd, long long dstride,
+                                                           const long long* __restrict__ ci, long long istride,
+                                                           int g, int k,
+                                                           long long* __restrict__ out_idx,
+                                                           float* __restrict__ out_dist) {
+  const int q = blockIdx.x;
+  for (int t = threadIdx.x; t < k; t += blockDim.x) { out_idx[(size_t)q * k + t] = -1; out_dist[(size_t)q * k + t] = INFINITY; }
+  __syncthreads();
+  for (int t = threadIdx.x; t < g * k; t += blockDim.x) {
+    const int a = t / k, p = t - a * k;
+    const long long id = ci[(size_t)a * istride + (size_t)q * k + p];
+    if (id < 0) continue;
+    const float d = cd[(size_t)a * dstride + (size_t)q * k + p];
+    int rank = p;
+    for (int s = 0; s < g; ++s) {
+      if (s == a) continue;
+      const float* od = cd + (size_t)s * dstride + (size_t)q * k;
+      const long long* oi = ci + (size_t)s * istride + (size_t)q * k;
+      int lo = 0, hi = k;  // count entries of list s that are better than (d,id)
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const long long mi = oi[mid];
+        const bool mb = (mi >= 0) && dist_better(od[mid], mi, d, id);
+        if (mb) lo = mid + 1; else hi = mid;
+      }
+      rank += lo;
+    }
+    if (rank < k) { out_idx[(size_t)q * k + rank] = id; out_dist[(size_t)q * k + rank] = d; }
+  }
+}
+
+// ---- add path -------------------------------------------------------------
+// L2-normalise rows (fp64 sum, 1/(sqrt+1e-30) as cosine space prescribes) and
+// store fp32 and/or bf16 copies with leading dimension ld (zero padded).
+__device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+__global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __restrict__ in, int in_ld, long long n,
+                                                             int dim, int ld, float* __restrict__ out_f32,
+                                                             uint16_t* __restrict__ out_bf16) {
+  const int lane = lane_id();
+  const long long w = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const long long nw = (long long)gridDim.x * (blockDim.x >> 6);
+  for (long long r = w; r < n; r += nw) {
+    const float* x = in + r * in_ld;
+    double ss = 0.0;
+    for (int c = lane; c < dim; c += 64) { const double v = (double)x[c]; ss += v * v; }
+    ss = wave_sum_f64(ss);
+    const double inv = 1.0 / (sqrt(ss) + 1e-30);
+    for (int c = lane; c < ld; c += 64) {
+      const float y = c < dim ? (float)((double)x[c] * inv) : 0.f;
+      if (out_f32) out_f32[r * ld + c] = y;
+      if (out_bf16) out_bf16[r * ld + c] = f32_to_bf16_rne(y);
+    }
+  }
+}
+
+// copy stored rows (already normalised) into a query buffer as fp32
+__global__ void rows_to_f32_kernel(const float* __restrict__ rows_f32, const uint16_t* __restrict__ rows_bf16,
+                                   int ld, long long row0, int n, float* __restrict__ out) {
+  const long long total = (long long)n * ld;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long src = row0 * ld + i;
+    out[i] = rows_f32 ? rows_f32[src] : __uint_as_float((uint32_t)rows_bf16[src] << 16);
+  }
+}
+
+// gather rows by index -> dense fp32 [n][dim]
+__global__ void gather_rows_kernel(const float* __restrict__ rows_f32, const uint16_t* __restrict__ rows_bf16,
+                                   int ld, int dim, const long long* __restrict__ idx, long long n,
+                                   float* __restrict__ out) {
+  const int lane = lane_id();
+  const long long w = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const long long nw = (long long)gridDim.x * (blockDim.x >> 6);
+  for (long long r = w; r < n; r += nw) {
+    const long long src = idx[r];
+    for (int c = lane; c < dim; c += 64)
+      out[r * dim + c] = rows_f32 ? rows_f32[src * ld + c] : __uint_as_float((uint32_t)rows_bf16[src * ld + c] << 16);
+  }
+}
+
+__global__ void fill_empty_kernel(long long* __restrict__ out_idx, float* __restrict__ out_dist, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { out_idx[i] = -1; out_dist[i] = INFINITY; }
+}
+
+// load path: rows on file are already unit vectors -> copy verbatim (+ derive bf16), pad to ld
+__global__ __launch_bounds__(256) void copy_rows_kernel(const float* __restrict__ in, long long n, int dim, int ld,
+                                                        float* __restrict__ out_f32, uint16_t* __restrict__ out_bf16) {
+  const int lane = lane_id();
+  const long long w = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const long long nw = (long long)gridDim.x * (blockDim.x >> 6);
+  for (long long r = w; r < n; r += nw)
+    for (int c = lane; c < ld; c += 64) {
+      const float y = c < dim ? in[r * dim + c] : 0.f;
+      if (out_f32) out_f32[r * ld + c] = y;
+      if (out_bf16) out_bf16[r * ld + c] = f32_to_bf16_rne(y);
+    }
+}
+
+}  // namespace vdbk

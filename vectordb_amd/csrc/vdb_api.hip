@@ -1,0 +1,669 @@
+// vdb_api.hip — C ABI (include/vdb.h) of the MI355X-native cosine top-k engine.
+// Host-side orchestration only: all arithmetic is in the HIP kernels of
+// scan_gemv.h / scan_mfma.h / select.h.  gfx950 only; no CPU fallback.
+#include <hip/hip_runtime.h>
+#include <sys/stat.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/vdb.h"
+#include "scan_gemv.h"
+#include "select.h"
+#include "synth.h"
+#include "scan_mfma.h"
+
+using namespace vdbk;
+
+namespace {
+
+thread_local std::string g_err;
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+}  // namespace
+
+struct vdb {
+  int dim = 0, ld = 0, dtype = 0, keep_f32 = 0, device = 0;
+  int64_t n = 0, cap = 0, row_offset = 0;
+  float* rows_f32 = nullptr;      // [cap][ld] normalised fp32 (dtype f32, or rerank copy)
+  uint16_t* rows_bf16 = nullptr;  // [cap][ld] bf16 (dtype bf16)
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  bool timing_valid = false;
+  double last_bytes = 0.0;
+  int n_cu = 256;
+  // options
+  int scan_blocks_per_cu = 4;
+  int scan_nt_loads = 1;
+  int batch_mfma_min_b = 16;
+  // workspaces (grown on demand)
+  DevBuf w_q, w_part_s, w_part_i, w_part2_s, w_part2_i, w_stage, w_out_i, w_out_d, w_idx, w_mfma;
+  std::string err;
+};
+
+namespace {
+
+int fail(vdb_t* h, int code, const std::string& msg) {
+  if (h) h->err = msg; else g_err = msg;
+  return code;
+}
+
+#define HIP_TRY(h, expr)                                                                          \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess)                                                                         \
+      return fail((h), e_ == hipErrorOutOfMemory ? VDB_ERR_MEMORY : VDB_ERR_DEVICE,               \
+                  std::string(#expr) + ": " + hipGetErrorString(e_));                             \
+  } while (0)
+
+int ensure(vdb_t* h, DevBuf& b, size_t bytes) {
+  if (bytes <= b.bytes) return VDB_OK;
+  if (b.p) { HIP_TRY(h, hipStreamSynchronize(h->stream)); HIP_TRY(h, hipFree(b.p)); b.p = nullptr; b.bytes = 0; }
+  size_t want = std::max(bytes, (size_t)4096);
+  HIP_TRY(h, hipMalloc(&b.p, want));
+  b.bytes = want;
+  return VDB_OK;
+}
+
+int set_device(vdb_t* h) {
+  HIP_TRY(h, hipSetDevice(h->device));
+  return VDB_OK;
+}
+
+int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+int grow(vdb_t* h, int64_t want_rows) {
+  if (want_rows <= h->cap) return VDB_OK;
+  const size_t ld = (size_t)h->ld;
+  if (h->keep_f32) {
+    float* p = nullptr;
+    HIP_TRY(h, hipMalloc((void**)&p, sizeof(float) * ld * (size_t)want_rows));
+    if (h->n) HIP_TRY(h, hipMemcpyAsync(p, h->rows_f32, sizeof(float) * ld * (size_t)h->n, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->rows_f32) HIP_TRY(h, hipFree(h->rows_f32));
+    h->rows_f32 = p;
+  }
+  if (h->dtype == VDB_BF16) {
+    uint16_t* p = nullptr;
+    HIP_TRY(h, hipMalloc((void**)&p, sizeof(uint16_t) * ld * (size_t)want_rows));
+    if (h->n) HIP_TRY(h, hipMemcpyAsync(p, h->rows_bf16, sizeof(uint16_t) * ld * (size_t)h->n, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->rows_bf16) HIP_TRY(h, hipFree(h->rows_bf16));
+    h->rows_bf16 = p;
+  }
+  h->cap = want_rows;
+  return VDB_OK;
+}
+
+int reserve_for_add(vdb_t* h, int64_t n) {
+  if (h->n + n > (int64_t)0x7ffffff0) return fail(h, VDB_ERR_ARG, "add: a shard holds at most 2^31-16 rows");
+  if (h->n + n <= h->cap) return VDB_OK;
+  int64_t want = h->cap + h->cap / 2;
+  if (want < h->n + n) want = h->n + n;
+  return grow(h, want);
+}
+
+// normalise n raw rows (device, leading dim in_ld) into the store at row h->n
+int normalize_into_store(vdb_t* h, const float* raw_dev, int in_ld, int64_t n, hipStream_t st) {
+  if (n == 0) return VDB_OK;
+  const int blocks = (int)std::min<int64_t>((n + 3) / 4, (int64_t)h->n_cu * 8);
+  float* of = h->keep_f32 ? h->rows_f32 + (size_t)h->n * h->ld : nullptr;
+  uint16_t* ob = h->dtype == VDB_BF16 ? h->rows_bf16 + (size_t)h->n * h->ld : nullptr;
+  hipLaunchKernelGGL(normalize_rows_kernel, dim3(blocks), dim3(256), 0, st, raw_dev, in_ld, (long long)n, h->dim, h->ld, of, ob);
+  HIP_TRY(h, hipGetLastError());
+  return VDB_OK;
+}
+
+// ---- scan dispatch ---------------------------------------------------------
+struct ScanArgs {
+  const void* rows; int n_rows; const float* qn; int kk; int self0; float* part_s; int* part_i;
+  int grid; hipStream_t st; size_t smem;
+};
+
+template <typename T, int DIM, int QB, int E>
+void launch_scan_t(const ScanArgs& a, bool nt) {
+  if (nt)
+    hipLaunchKernelGGL((scan_topk_kernel<T, DIM, QB, E, true>), dim3(a.grid), dim3(kScanThreads), a.smem, a.st, a.rows, a.n_rows, a.qn, a.kk, a.self0, a.part_s, a.part_i);
+  else
+    hipLaunchKernelGGL((scan_topk_kernel<T, DIM, QB, E, false>), dim3(a.grid), dim3(kScanThreads), a.smem, a.st, a.rows, a.n_rows, a.qn, a.kk, a.self0, a.part_s, a.part_i);
+}
+
+template <typename T, int DIM>
+bool launch_scan_dim(const ScanArgs& a, int qb, int e, bool nt) {
+  if (qb == 1) {
+    switch (e) {
+      case 1: launch_scan_t<T, DIM, 1, 1>(a, nt); return true;
+      case 2: launch_scan_t<T, DIM, 1, 2>(a, nt); return true;
+      case 4: launch_scan_t<T, DIM, 1, 4>(a, nt); return true;
+      case 8: launch_scan_t<T, DIM, 1, 8>(a, nt); return true;
+      case 16: launch_scan_t<T, DIM, 1, 16>(a, nt); return true;
+    }
+  } else if (qb == 2) {
+    switch (e) {
+      case 1: launch_scan_t<T, DIM, 2, 1>(a, nt); return true;
+      case 2: launch_scan_t<T, DIM, 2, 2>(a, nt); return true;
+    }
+  } else if (qb == 4) {
+    switch (e) {
+      case 1: launch_scan_t<T, DIM, 4, 1>(a, nt); return true;
+      case 2: launch_scan_t<T, DIM, 4, 2>(a, nt); return true;
+    }
+  }
+  return false;
+}
+
+template <typename T>
+bool launch_scan_generic(const ScanArgs& a, int ld, int e, bool nt) {
+#define GEN_CASE(EE)                                                                                              \
+  case EE:                                                                                                        \
+    if (nt) hipLaunchKernelGGL((scan_topk_generic_kernel<T, EE, true>), dim3(a.grid), dim3(kScanThreads), a.smem, a.st, a.rows, a.n_rows, ld, a.qn, a.kk, a.self0, a.part_s, a.part_i); \
+    else hipLaunchKernelGGL((scan_topk_generic_kernel<T, EE, false>), dim3(a.grid), dim3(kScanThreads), a.smem, a.st, a.rows, a.n_rows, ld, a.qn, a.kk, a.self0, a.part_s, a.part_i);   \
+    return true;
+  switch (e) { GEN_CASE(1) GEN_CASE(2) GEN_CASE(4) GEN_CASE(8) GEN_CASE(16) }
+#undef GEN_CASE
+  return false;
+}
+
+int entries_for(int kk) {
+  int e = (kk + 63) / 64;
+  int p = 1;
+  while (p < e) p <<= 1;
+  return p;  // 1,2,4,8,16
+}
+
+template <int E>
+void launch_merge_t(const float* is, const int* ii, int n_cand, int cpb, int kk, float* os, int* oi, int gx, int b, hipStream_t st) {
+  const size_t smem = (size_t)kMergeWaves * kk * 8;
+  hipLaunchKernelGGL((merge_lists_kernel<E>), dim3(gx, b), dim3(kMergeThreads), smem, st, is, ii, n_cand, cpb, kk, os, oi);
+}
+void launch_merge(int e, const float* is, const int* ii, int n_cand, int cpb, int kk, float* os, int* oi, int gx, int b, hipStream_t st) {
+  switch (e) {
+    case 1: launch_merge_t<1>(is, ii, n_cand, cpb, kk, os, oi, gx, b, st); break;
+    case 2: launch_merge_t<2>(is, ii, n_cand, cpb, kk, os, oi, gx, b, st); break;
+    case 4: launch_merge_t<4>(is, ii, n_cand, cpb, kk, os, oi, gx, b, st); break;
+    case 8: launch_merge_t<8>(is, ii, n_cand, cpb, kk, os, oi, gx, b, st); break;
+    default: launch_merge_t<16>(is, ii, n_cand, cpb, kk, os, oi, gx, b, st); break;
+  }
+}
+
+// Reduce [b][n_parts][kk] partial lists to [b][kk]; returns pointers to the result.
+int merge_partials(vdb_t* h, int b, int n_parts, int kk, hipStream_t st, float** res_s, int** res_i) {
+  float* cur_s = (float*)h->w_part_s.p;
+  int* cur_i = (int*)h->w_part_i.p;
+  float* oth_s = (float*)h->w_part2_s.p;
+  int* oth_i = (int*)h->w_part2_i.p;
+  const int e = entries_for(kk);
+  int lists = n_parts;
+  while (lists > 1) {
+    const int lists_per_block = std::max(2, std::min(lists, std::max(32, 4096 / kk)));
+    const int gx = (lists + lists_per_block - 1) / lists_per_block;
+    launch_merge(e, cur_s, cur_i, lists * kk, lists_per_block * kk, kk, oth_s, oth_i, gx, b, st);
+    HIP_TRY(h, hipGetLastError());
+    std::swap(cur_s, oth_s);
+    std::swap(cur_i, oth_i);
+    lists = gx;
+  }
+  *res_s = cur_s;
+  *res_i = cur_i;
+  return VDB_OK;
+}
+
+// Core search over device-resident, already *normalised* queries qn [b][ld].
+// self_row0 >= 0: query q excludes row self_row0+q.
+int search_core(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_row0, int64_t* out_idx,
+                float* out_dist, hipStream_t st) {
+  const int kk = kp ? kp : k;
+  const int e = entries_for(kk);
+  const bool bf16 = h->dtype == VDB_BF16;
+  const void* rows = bf16 ? (const void*)h->rows_bf16 : (const void*)h->rows_f32;
+  const int n_rows = (int)h->n;
+  const bool fast_dim = (h->ld == h->dim) && (h->dim == 768 || h->dim == 384);
+
+  HIP_TRY(h, hipEventRecord(h->ev[0], st));
+  h->last_bytes = 0.0;
+
+  if (n_rows == 0) {
+    // empty store: all -1 / +inf
+    hipLaunchKernelGGL(fill_empty_kernel, dim3((b * k + 255) / 256), dim3(256), 0, st, (long long*)out_idx, out_dist, (long long)b * k);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipEventRecord(h->ev[1], st));
+    HIP_TRY(h, hipEventRecord(h->ev[2], st));
+    h->timing_valid = true;
+    return VDB_OK;
+  }
+
+  // MFMA batched path (bf16 store, fast dim, enough queries)
+  if (bf16 && h->dim == 768 && h->ld == 768 && b >= h->batch_mfma_min_b && mfma_path_supported(kk)) {
+    int rc = mfma_search(h, qn, b, k, kp, self_row0, out_idx, out_dist, st);
+    return rc;
+  }
+
+  // grid: enough blocks to fill the chip, never more tiles than work
+  const int rows_per_block_min = 64;
+  int grid = h->n_cu * h->scan_blocks_per_cu;
+  grid = (int)std::max<int64_t>(1, std::min<int64_t>(grid, ((int64_t)n_rows + rows_per_block_min - 1) / rows_per_block_min));
+
+  // queries are processed in chunks so the partial buffers stay small
+  const int qchunk = 64;
+  const int cb_max = std::min(b, qchunk);
+  const size_t part_elems = (size_t)cb_max * grid * kk;
+  int rc;
+  if ((rc = ensure(h, h->w_part_s, part_elems * 4))) return rc;
+  if ((rc = ensure(h, h->w_part_i, part_elems * 4))) return rc;
+  if ((rc = ensure(h, h->w_part2_s, part_elems * 4))) return rc;
+  if ((rc = ensure(h, h->w_part2_i, part_elems * 4))) return rc;
+
+  for (int q0 = 0; q0 < b; q0 += qchunk) {
+    const int cb = std::min(qchunk, b - q0);
+    // --- scan passes -------------------------------------------------------
+    int q = 0;
+    while (q < cb) {
+      int qb = 1;
+      if (fast_dim && e <= 2) { if (cb - q >= 4) qb = 4; else if (cb - q >= 2) qb = 2; }
+      ScanArgs a;
+      a.rows = rows; a.n_rows = n_rows; a.qn = qn + (size_t)(q0 + q) * h->ld; a.kk = kk;
+      a.self0 = self_row0 >= 0 ? (int)(self_row0 + q0 + q) : -1;
+      a.part_s = (float*)h->w_part_s.p + (size_t)q * grid * kk;
+      a.part_i = (int*)h->w_part_i.p + (size_t)q * grid * kk;
+      a.grid = grid; a.st = st;
+      a.smem = (size_t)kScanWaves * qb * kk * 8;
+      bool ok;
+      const bool nt = h->scan_nt_loads != 0;
+      if (fast_dim) {
+        if (h->dim == 768) ok = bf16 ? launch_scan_dim<bf16_t, 768>(a, qb, e, nt) : launch_scan_dim<float, 768>(a, qb, e, nt);
+        else ok = bf16 ? launch_scan_dim<bf16_t, 384>(a, qb, e, nt) : launch_scan_dim<float, 384>(a, qb, e, nt);
+      } else {
+        a.smem = (size_t)kScanWaves * kk * 8 + (size_t)h->ld * 4;
+        ok = bf16 ? launch_scan_generic<bf16_t>(a, h->ld, e, nt) : launch_scan_generic<float>(a, h->ld, e, nt);
+      }
+      if (!ok) return fail(h, VDB_ERR_ARG, "search: unsupported k for this path");
+      HIP_TRY(h, hipGetLastError());
+      h->last_bytes += (double)n_rows * h->ld * (bf16 ? 2 : 4);
+      q += qb;
+    }
+    if (q0 == 0 && b <= qchunk) HIP_TRY(h, hipEventRecord(h->ev[1], st));
+    // --- merge + finish ----------------------------------------------------
+    float* ms; int* mi;
+    if ((rc = merge_partials(h, cb, grid, kk, st, &ms, &mi))) return rc;
+    int64_t* oi = out_idx + (size_t)q0 * k;
+    float* od = out_dist + (size_t)q0 * k;
+    if (kp) {
+      hipLaunchKernelGGL(rerank_kernel, dim3(cb), dim3(256), (size_t)kk * 8, st, h->rows_f32, h->ld,
+                         qn + (size_t)q0 * h->ld, mi, kk, k, (long long)h->row_offset, (long long*)oi, od);
+    } else {
+      hipLaunchKernelGGL(finalize_kernel, dim3(cb), dim3(256), (size_t)kk * 8, st, ms, mi, kk, k,
+                         (long long)h->row_offset, (long long*)oi, od);
+    }
+    HIP_TRY(h, hipGetLastError());
+  }
+  if (b > qchunk) HIP_TRY(h, hipEventRecord(h->ev[1], st));  // multi-chunk: scan/merge interleave, report total as scan
+  HIP_TRY(h, hipEventRecord(h->ev[2], st));
+  h->timing_valid = true;
+  return VDB_OK;
+}
+
+int check_search_args(vdb_t* h, const void* q, int b, int k, int kp, const void* oi, const void* od) {
+  if (b < 0 || (b > 0 && (!q || !oi || !od))) return fail(h, VDB_ERR_ARG, "search: NULL buffer");
+  if (k < 1 || k > VDB_MAX_K) return fail(h, VDB_ERR_ARG, "search: k must be in [1,1024]");
+  if (kp != 0 && (kp < k || kp > VDB_MAX_K)) return fail(h, VDB_ERR_ARG, "search: rerank_kprime must be 0 or in [k,1024]");
+  if (kp != 0 && !(h->dtype == VDB_BF16 && h->keep_f32)) return fail(h, VDB_ERR_STATE, "search: rerank needs a bf16 store created with keep_f32_for_rerank");
+  return VDB_OK;
+}
+
+// normalise raw device queries [b][dim] into the handle's query workspace [b][ld]
+int prep_queries(vdb_t* h, const float* q_dev, int b, hipStream_t st, float** qn) {
+  int rc = ensure(h, h->w_q, (size_t)std::max(b, 1) * h->ld * 4);
+  if (rc) return rc;
+  float* out = (float*)h->w_q.p;
+  const int blocks = std::max(1, std::min((b + 3) / 4, h->n_cu * 8));
+  hipLaunchKernelGGL(normalize_rows_kernel, dim3(blocks), dim3(256), 0, st, q_dev, h->dim, (long long)b, h->dim, h->ld, out, (uint16_t*)nullptr);
+  HIP_TRY(h, hipGetLastError());
+  *qn = out;
+  return VDB_OK;
+}
+
+}  // namespace
+
+// ===========================================================================
+extern "C" {
+
+int vdb_create(vdb_t** out, int dim, int dtype, int keep_f32, int device_id) {
+  if (!out) return fail(nullptr, VDB_ERR_ARG, "vdb_create: out is NULL");
+  if (dim <= 0 || dim > 65536) return fail(nullptr, VDB_ERR_ARG, "vdb_create: dim must be in [1,65536]");
+  if (dtype != VDB_F32 && dtype != VDB_BF16) return fail(nullptr, VDB_ERR_ARG, "vdb_create: dtype must be 0 (f32) or 1 (bf16)");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0)
+    return fail(nullptr, VDB_ERR_DEVICE, std::string("vdb_create: no HIP device available (") + hipGetErrorString(e) + "); this library has no CPU fallback");
+  if (device_id < 0 || device_id >= ndev) return fail(nullptr, VDB_ERR_ARG, "vdb_create: device_id out of range");
+  vdb_t* h = new (std::nothrow) vdb();
+  if (!h) return fail(nullptr, VDB_ERR_MEMORY, "vdb_create: out of host memory");
+  h->dim = dim; h->ld = round_up(dim, 8); h->dtype = dtype;
+  h->keep_f32 = (dtype == VDB_F32) ? 1 : (keep_f32 != 0);
+  h->device = device_id;
+  hipDeviceProp_t prop;
+  if (hipSetDevice(device_id) != hipSuccess || hipGetDeviceProperties(&prop, device_id) != hipSuccess ||
+      hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete h;
+    return fail(nullptr, VDB_ERR_DEVICE, "vdb_create: device initialisation failed");
+  }
+  h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  for (int i = 0; i < 3; ++i)
+    if (hipEventCreate(&h->ev[i]) != hipSuccess) { vdb_destroy(h); return fail(nullptr, VDB_ERR_DEVICE, "vdb_create: event creation failed"); }
+  *out = h;
+  return VDB_OK;
+}
+
+void vdb_destroy(vdb_t* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  DevBuf* bufs[] = {&h->w_q, &h->w_part_s, &h->w_part_i, &h->w_part2_s, &h->w_part2_i, &h->w_stage, &h->w_out_i, &h->w_out_d, &h->w_idx, &h->w_mfma};
+  for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
+  if (h->rows_f32) (void)hipFree(h->rows_f32);
+  if (h->rows_bf16) (void)hipFree(h->rows_bf16);
+  for (int i = 0; i < 3; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+const char* vdb_last_error(vdb_t* h) { return h ? h->err.c_str() : g_err.c_str(); }
+
+int vdb_reserve(vdb_t* h, int64_t n_rows) {
+  if (!h) return VDB_ERR_ARG;
+  if (n_rows < 0 || n_rows > (int64_t)0x7ffffff0) return fail(h, VDB_ERR_ARG, "reserve: n_rows out of range");
+  int rc = set_device(h);
+  if (rc) return rc;
+  return grow(h, n_rows);
+}
+
+int vdb_set_row_offset(vdb_t* h, int64_t off) {
+  if (!h) return VDB_ERR_ARG;
+  h->row_offset = off;
+  return VDB_OK;
+}
+
+int vdb_add(vdb_t* h, const float* rows_host, int64_t n) {
+  if (!h) return VDB_ERR_ARG;
+  if (n < 0 || (n > 0 && !rows_host)) return fail(h, VDB_ERR_ARG, "vdb_add: bad rows/n");
+  if (n == 0) return VDB_OK;
+  int rc = set_device(h);
+  if (rc) return rc;
+  if ((rc = reserve_for_add(h, n))) return rc;
+  // stage in bounded chunks: H2D -> normalise(+convert) into the store
+  const int64_t chunk_rows = std::max<int64_t>(1, (int64_t)(64u << 20) / ((int64_t)h->dim * 4));
+  if ((rc = ensure(h, h->w_stage, (size_t)std::min(n, chunk_rows) * h->dim * 4))) return rc;
+  for (int64_t r = 0; r < n; r += chunk_rows) {
+    const int64_t m = std::min(chunk_rows, n - r);
+    HIP_TRY(h, hipMemcpyAsync(h->w_stage.p, rows_host + (size_t)r * h->dim, (size_t)m * h->dim * 4, hipMemcpyHostToDevice, h->stream));
+    if ((rc = normalize_into_store(h, (const float*)h->w_stage.p, h->dim, m, h->stream))) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));  // staging buffer is reused
+    h->n += m;
+  }
+  return VDB_OK;
+}
+
+int vdb_add_dev(vdb_t* h, const float* rows_dev, int64_t n) {
+  if (!h) return VDB_ERR_ARG;
+  if (n < 0 || (n > 0 && !rows_dev)) return fail(h, VDB_ERR_ARG, "vdb_add_dev: bad rows/n");
+  if (n == 0) return VDB_OK;
+  int rc = set_device(h);
+  if (rc) return rc;
+  if ((rc = reserve_for_add(h, n))) return rc;
+  if ((rc = normalize_into_store(h, rows_dev, h->dim, n, h->stream))) return rc;
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  h->n += n;
+  return VDB_OK;
+}
+
+int vdb_count(vdb_t* h, int64_t* n) {
+  if (!h || !n) return VDB_ERR_ARG;
+  *n = h->n;
+  return VDB_OK;
+}
+
+int vdb_search_dev(vdb_t* h, const float* queries_dev, int b, int k, int kp, int64_t* out_idx_dev,
+                   float* out_dist_dev, void* stream) {
+  if (!h) return VDB_ERR_ARG;
+  int rc = check_search_args(h, queries_dev, b, k, kp, out_idx_dev, out_dist_dev);
+  if (rc) return rc;
+  if (b == 0) return VDB_OK;
+  if ((rc = set_device(h))) return rc;
+  hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+  float* qn = nullptr;
+  if ((rc = prep_queries(h, queries_dev, b, st, &qn))) return rc;
+  return search_core(h, qn, b, k, kp, -1, out_idx_dev, out_dist_dev, st);
+}
+
+int vdb_search(vdb_t* h, const float* queries_host, int b, int k, int kp, int64_t* out_idx, float* out_dist) {
+  if (!h) return VDB_ERR_ARG;
+  int rc = check_search_args(h, queries_host, b, k, kp, out_idx, out_dist);
+  if (rc) return rc;
+  if (b == 0) return VDB_OK;
+  if ((rc = set_device(h))) return rc;
+  if ((rc = ensure(h, h->w_stage, (size_t)b * h->dim * 4))) return rc;
+  if ((rc = ensure(h, h->w_out_i, (size_t)b * k * 8))) return rc;
+  if ((rc = ensure(h, h->w_out_d, (size_t)b * k * 4))) return rc;
+  HIP_TRY(h, hipMemcpyAsync(h->w_stage.p, queries_host, (size_t)b * h->dim * 4, hipMemcpyHostToDevice, h->stream));
+  float* qn = nullptr;
+  if ((rc = prep_queries(h, (const float*)h->w_stage.p, b, h->stream, &qn))) return rc;
+  if ((rc = search_core(h, qn, b, k, kp, -1, (int64_t*)h->w_out_i.p, (float*)h->w_out_d.p, h->stream))) return rc;
+  HIP_TRY(h, hipMemcpyAsync(out_idx, h->w_out_i.p, (size_t)b * k * 8, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(out_dist, h->w_out_d.p, (size_t)b * k * 4, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return VDB_OK;
+}
+
+int vdb_merge_topk_dev(vdb_t* h, const float* cd, int64_t dstride, const int64_t* ci, int64_t istride, int g,
+                       int b, int k, int64_t* oi, float* od, void* stream) {
+  if (!h) return VDB_ERR_ARG;
+  if (g < 1 || b < 0 || k < 1 || k > VDB_MAX_K) return fail(h, VDB_ERR_ARG, "merge: bad g/b/k");
+  if (b > 0 && (!cd || !ci || !oi || !od)) return fail(h, VDB_ERR_ARG, "merge: NULL buffer");
+  if (b == 0) return VDB_OK;
+  int rc = set_device(h);
+  if (rc) return rc;
+  hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+  if (dstride < 0 || istride < 0) return fail(h, VDB_ERR_ARG, "merge: negative stride");
+  hipLaunchKernelGGL(merge_shards_kernel, dim3(b), dim3(256), 0, st, cd, (long long)(dstride ? dstride : (int64_t)b * k),
+                     (const long long*)ci, (long long)(istride ? istride : (int64_t)b * k), g, k, (long long*)oi, od);
+  HIP_TRY(h, hipGetLastError());
+  return VDB_OK;
+}
+
+int vdb_selfjoin(vdb_t* h, int64_t q_row0, int64_t q_n, int k, int exclude_self, int kp, int64_t* out_idx,
+                 float* out_dist) {
+  if (!h) return VDB_ERR_ARG;
+  if (q_row0 < 0 || q_n < 0 || q_row0 + q_n > h->n) return fail(h, VDB_ERR_ARG, "selfjoin: query range outside the store");
+  int rc = check_search_args(h, h, q_n > 0 ? 1 : 0, k, kp, out_idx, out_dist);
+  if (rc) return rc;
+  if (q_n == 0) return VDB_OK;
+  if ((rc = set_device(h))) return rc;
+  const int qblock = 4096;  // queries per pass
+  if ((rc = ensure(h, h->w_q, (size_t)qblock * h->ld * 4))) return rc;
+  if ((rc = ensure(h, h->w_out_i, (size_t)qblock * k * 8))) return rc;
+  if ((rc = ensure(h, h->w_out_d, (size_t)qblock * k * 4))) return rc;
+  for (int64_t q0 = 0; q0 < q_n; q0 += qblock) {
+    const int cb = (int)std::min<int64_t>(qblock, q_n - q0);
+    // stored rows are unit vectors already: copy them as the normalised queries
+    hipLaunchKernelGGL(rows_to_f32_kernel, dim3(std::min(4096, (cb * h->ld + 255) / 256)), dim3(256), 0, h->stream,
+                       h->keep_f32 ? h->rows_f32 : nullptr, h->rows_bf16, h->ld, (long long)(q_row0 + q0), cb, (float*)h->w_q.p);
+    HIP_TRY(h, hipGetLastError());
+    if ((rc = search_core(h, (const float*)h->w_q.p, cb, k, kp, exclude_self ? q_row0 + q0 : -1,
+                          (int64_t*)h->w_out_i.p, (float*)h->w_out_d.p, h->stream))) return rc;
+    HIP_TRY(h, hipMemcpyAsync(out_idx + (size_t)q0 * k, h->w_out_i.p, (size_t)cb * k * 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(out_dist + (size_t)q0 * k, h->w_out_d.p, (size_t)cb * k * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+  }
+  return VDB_OK;
+}
+
+int vdb_fetch(vdb_t* h, const int64_t* idx_host, int64_t n, float* out_rows_host) {
+  if (!h) return VDB_ERR_ARG;
+  if (n < 0 || (n > 0 && (!idx_host || !out_rows_host))) return fail(h, VDB_ERR_ARG, "fetch: NULL buffer");
+  for (int64_t j = 0; j < n; ++j)
+    if (idx_host[j] < 0 || idx_host[j] >= h->n) return fail(h, VDB_ERR_ARG, "fetch: index out of range");
+  if (n == 0) return VDB_OK;
+  int rc = set_device(h);
+  if (rc) return rc;
+  const int64_t chunk = std::max<int64_t>(1, (int64_t)(64u << 20) / ((int64_t)h->dim * 4));
+  if ((rc = ensure(h, h->w_idx, (size_t)std::min(n, chunk) * 8))) return rc;
+  if ((rc = ensure(h, h->w_stage, (size_t)std::min(n, chunk) * h->dim * 4))) return rc;
+  for (int64_t r = 0; r < n; r += chunk) {
+    const int64_t m = std::min(chunk, n - r);
+    HIP_TRY(h, hipMemcpyAsync(h->w_idx.p, idx_host + r, (size_t)m * 8, hipMemcpyHostToDevice, h->stream));
+    const int blocks = (int)std::min<int64_t>((m + 3) / 4, (int64_t)h->n_cu * 8);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(blocks), dim3(256), 0, h->stream, h->keep_f32 ? h->rows_f32 : nullptr,
+                       h->rows_bf16, h->ld, h->dim, (const long long*)h->w_idx.p, (long long)m, (float*)h->w_stage.p);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(out_rows_host + (size_t)r * h->dim, h->w_stage.p, (size_t)m * h->dim * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+  }
+  return VDB_OK;
+}
+
+// ---- persistence: 32-byte header + unpadded rows (shared with the oracle) --
+struct vdb_file_header { char magic[8]; int32_t dim; int32_t stored_dtype; int64_t n; int64_t row_offset; };
+
+int vdb_save(vdb_t* h, const char* dir) {
+  if (!h || !dir) return VDB_ERR_ARG;
+  int rc = set_device(h);
+  if (rc) return rc;
+  mkdir(dir, 0777);
+  const std::string path = std::string(dir) + "/vectors.vdb";
+  FILE* f = fopen(path.c_str(), "wb");
+  if (!f) return fail(h, VDB_ERR_IO, "save: cannot open " + path);
+  vdb_file_header hd;
+  memset(&hd, 0, sizeof hd);
+  memcpy(hd.magic, "VDBFLAT1", 8);
+  hd.dim = h->dim; hd.stored_dtype = h->keep_f32 ? VDB_F32 : VDB_BF16; hd.n = h->n; hd.row_offset = h->row_offset;
+  bool ok = fwrite(&hd, sizeof hd, 1, f) == 1;
+  const size_t esz = h->keep_f32 ? 4 : 2;
+  const int64_t chunk = std::max<int64_t>(1, (int64_t)(64u << 20) / ((int64_t)h->dim * 4));
+  std::vector<unsigned char> host((size_t)std::min<int64_t>(std::max<int64_t>(h->n, 1), chunk) * h->dim * esz);
+  for (int64_t r = 0; ok && r < h->n; r += chunk) {
+    const int64_t m = std::min(chunk, h->n - r);
+    const unsigned char* src = h->keep_f32 ? (const unsigned char*)(h->rows_f32 + (size_t)r * h->ld)
+                                           : (const unsigned char*)(h->rows_bf16 + (size_t)r * h->ld);
+    hipError_t e = hipMemcpy2DAsync(host.data(), (size_t)h->dim * esz, src, (size_t)h->ld * esz, (size_t)h->dim * esz, (size_t)m, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) { fclose(f); return fail(h, VDB_ERR_DEVICE, std::string("save: ") + hipGetErrorString(e)); }
+    ok = fwrite(host.data(), esz, (size_t)m * h->dim, f) == (size_t)m * h->dim;
+  }
+  fclose(f);
+  return ok ? VDB_OK : fail(h, VDB_ERR_IO, "save: short write");
+}
+
+int vdb_load(vdb_t** out, const char* dir, int dtype, int keep_f32, int device_id) {
+  if (!out || !dir) return fail(nullptr, VDB_ERR_ARG, "load: NULL argument");
+  const std::string path = std::string(dir) + "/vectors.vdb";
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) return fail(nullptr, VDB_ERR_IO, "load: cannot open " + path);
+  vdb_file_header hd;
+  if (fread(&hd, sizeof hd, 1, f) != 1 || memcmp(hd.magic, "VDBFLAT1", 8) != 0) { fclose(f); return fail(nullptr, VDB_ERR_IO, "load: bad header"); }
+  if (hd.stored_dtype == VDB_BF16 && (dtype == VDB_F32 || keep_f32)) { fclose(f); return fail(nullptr, VDB_ERR_STATE, "load: file holds bf16 rows only; cannot rebuild fp32 rows"); }
+  vdb_t* h = nullptr;
+  int rc = vdb_create(&h, hd.dim, dtype, keep_f32, device_id);
+  if (rc) { fclose(f); return rc; }
+  h->row_offset = hd.row_offset;
+  auto bail = [&](int code, const std::string& msg) { g_err = msg; vdb_destroy(h); fclose(f); return code; };
+  if ((rc = grow(h, std::max<int64_t>(hd.n, 1)))) return bail(rc, h->err);
+  const int64_t chunk = std::max<int64_t>(1, (int64_t)(64u << 20) / ((int64_t)h->dim * 4));
+  if (hd.stored_dtype == VDB_F32) {
+    // rows on file are unit vectors; re-normalising is idempotent to <= 1 ulp, so
+    // the verbatim bits are kept for the fp32 copy and bf16 is derived from them.
+    std::vector<float> host((size_t)std::min<int64_t>(std::max<int64_t>(hd.n, 1), chunk) * hd.dim);
+    if ((rc = ensure(h, h->w_stage, host.size() * 4))) return bail(rc, h->err);
+    for (int64_t r = 0; r < hd.n; r += chunk) {
+      const int64_t m = std::min(chunk, hd.n - r);
+      if (fread(host.data(), 4, (size_t)m * hd.dim, f) != (size_t)m * hd.dim) return bail(VDB_ERR_IO, "load: short read");
+      hipError_t e = hipMemcpyAsync(h->w_stage.p, host.data(), (size_t)m * hd.dim * 4, hipMemcpyHostToDevice, h->stream);
+      if (e != hipSuccess) return bail(VDB_ERR_DEVICE, hipGetErrorString(e));
+      hipLaunchKernelGGL(copy_rows_kernel, dim3((int)std::min<int64_t>((m + 3) / 4, (int64_t)h->n_cu * 8)), dim3(256), 0, h->stream,
+                         (const float*)h->w_stage.p, (long long)m, h->dim, h->ld,
+                         h->keep_f32 ? h->rows_f32 + (size_t)r * h->ld : nullptr,
+                         h->dtype == VDB_BF16 ? h->rows_bf16 + (size_t)r * h->ld : nullptr);
+      e = hipStreamSynchronize(h->stream);
+      if (e != hipSuccess) return bail(VDB_ERR_DEVICE, hipGetErrorString(e));
+    }
+  } else {
+    std::vector<uint16_t> host((size_t)std::min<int64_t>(std::max<int64_t>(hd.n, 1), chunk) * hd.dim);
+    for (int64_t r = 0; r < hd.n; r += chunk) {
+      const int64_t m = std::min(chunk, hd.n - r);
+      if (fread(host.data(), 2, (size_t)m * hd.dim, f) != (size_t)m * hd.dim) return bail(VDB_ERR_IO, "load: short read");
+      hipError_t e = hipMemset2DAsync(h->rows_bf16 + (size_t)r * h->ld, (size_t)h->ld * 2, 0, (size_t)h->ld * 2, (size_t)m, h->stream);
+      if (e == hipSuccess) e = hipMemcpy2DAsync(h->rows_bf16 + (size_t)r * h->ld, (size_t)h->ld * 2, host.data(), (size_t)hd.dim * 2, (size_t)hd.dim * 2, (size_t)m, hipMemcpyHostToDevice, h->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+      if (e != hipSuccess) return bail(VDB_ERR_DEVICE, hipGetErrorString(e));
+    }
+  }
+  fclose(f);
+  h->n = hd.n;
+  *out = h;
+  return VDB_OK;
+}
+
+int vdb_last_timing(vdb_t* h, float* scan_ms, float* merge_ms, double* bytes) {
+  if (!h) return VDB_ERR_ARG;
+  if (!h->timing_valid) return fail(h, VDB_ERR_STATE, "last_timing: no search has run on this handle");
+  int rc = set_device(h);
+  if (rc) return rc;
+  HIP_TRY(h, hipEventSynchronize(h->ev[2]));
+  float a = 0.f, b = 0.f;
+  HIP_TRY(h, hipEventElapsedTime(&a, h->ev[0], h->ev[1]));
+  HIP_TRY(h, hipEventElapsedTime(&b, h->ev[1], h->ev[2]));
+  if (scan_ms) *scan_ms = a;
+  if (merge_ms) *merge_ms = b;
+  if (bytes) *bytes = h->last_bytes;
+  return VDB_OK;
+}
+
+int vdb_set_option(vdb_t* h, const char* name, int64_t value) {
+  if (!h || !name) return VDB_ERR_ARG;
+  if (!strcmp(name, "scan_blocks_per_cu")) { if (value < 1 || value > 32) return fail(h, VDB_ERR_ARG, "scan_blocks_per_cu must be in [1,32]"); h->scan_blocks_per_cu = (int)value; return VDB_OK; }
+  if (!strcmp(name, "scan_nt_loads")) { h->scan_nt_loads = value != 0; return VDB_OK; }
+  if (!strcmp(name, "batch_mfma_min_b")) { if (value < 1) return fail(h, VDB_ERR_ARG, "batch_mfma_min_b must be >= 1"); h->batch_mfma_min_b = (int)std::min<int64_t>(value, 1 << 30); return VDB_OK; }
+  return fail(h, VDB_ERR_ARG, std::string("set_option: unknown option ") + name);
+}
+
+int vdb_synth_rows_dev(vdb_t* h, float* out_dev, int64_t row0, int64_t n, const vdb_synth_spec* spec, void* stream) {
+  if (!h) return VDB_ERR_ARG;
+  if (!spec || n < 0 || (n > 0 && !out_dev)) return fail(h, VDB_ERR_ARG, "synth: bad arguments");
+  if (n == 0) return VDB_OK;
+  int rc = set_device(h);
+  if (rc) return rc;
+  hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+  const int blocks = (int)std::min<int64_t>((n + 3) / 4, (int64_t)h->n_cu * 8);
+  hipLaunchKernelGGL(synth_rows_kernel, dim3(blocks), dim3(256), 0, st, out_dev, (long long)row0, (long long)n, h->dim, h->dim, *spec);
+  HIP_TRY(h, hipGetLastError());
+  return VDB_OK;
+}
+
+int vdb_add_synth(vdb_t* h, int64_t row0, int64_t n, const vdb_synth_spec* spec) {
+  if (!h) return VDB_ERR_ARG;
+  if (!spec || n < 0) return fail(h, VDB_ERR_ARG, "add_synth: bad arguments");
+  if (n == 0) return VDB_OK;
+  int rc = set_device(h);
+  if (rc) return rc;
+  if ((rc = reserve_for_add(h, n))) return rc;
+  const int64_t chunk = std::max<int64_t>(1, (int64_t)(256u << 20) / ((int64_t)h->dim * 4));
+  if ((rc = ensure(h, h->w_stage, (size_t)std::min(n, chunk) * h->dim * 4))) return rc;
+  for (int64_t r = 0; r < n; r += chunk) {
+    const int64_t m = std::min(chunk, n - r);
+    const int blocks = (int)std::min<int64_t>((m + 3) / 4, (int64_t)h->n_cu * 8);
+    hipLaunchKernelGGL(synth_rows_kernel, dim3(blocks), dim3(256), 0, h->stream, (float*)h->w_stage.p, (long long)(row0 + r), (long long)m, h->dim, h->dim, *spec);
+    HIP_TRY(h, hipGetLastError());
+    if ((rc = normalize_into_store(h, (const float*)h->w_stage.p, h->dim, m, h->stream))) return rc;
+    h->n += m;
+  }
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return VDB_OK;
+}
+
+}  // extern "C"
