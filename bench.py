@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json's metric on MI355X: QPS @k=10 over a synthetic
+10M x 768 bf16 corpus (fp32 rerank, k'=40), batch 1 (default) or 1024.
+
+  python bench.py --gpus 1 --steps 200 --warmup 20
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one query batch: normalise the queries,
+scan the (row-sharded) corpus with the fused top-k' kernel, merge, fp32 rerank,
+and for N>1 one RCCL all-gather + on-device merge.  The corpus (10M rows in
+total, row-sharded over the ranks: strong scaling) and the queries are resident
+in HBM before the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from vectordb_amd import SynthSpec  # noqa: E402
+from vectordb_amd.distributed import ShardedIndex, shard_range  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_BF16_PEAK_TFLOPS = 2500.0
+
+
+def cpu_baseline(dim, k, target_rows, seed, budget_s=20.0):
+    """The CPU oracle (a port of the reference's algorithm: exact cosine top-k, fp32 storage,
+    fp64 accumulate, OpenMP over rows) timed on a bounded sample of the same workload."""
+    from oracle import oracle
+    sample_rows = 400_000
+    spec = SynthSpec(seed=seed, kind=1, n_clusters=int(np.sqrt(target_rows)), noise=0.3)
+    rows = oracle.normalize_rows(oracle.synth_rows(0, sample_rows, dim, spec))
+    qspec = SynthSpec(seed=seed + 1, kind=2, noise=0.5, base_kind=1, base_seed=seed, base_n=sample_rows,
+                      base_n_clusters=spec.n_clusters, base_noise=0.3)
+    queries = oracle.synth_rows(0, 64, dim, qspec)
+    oracle.exact_topk(rows, queries[:1], k)  # warm
+    t0 = time.perf_counter()
+    done = 0
+    while done < 64 and (time.perf_counter() - t0) < budget_s:
+        oracle.exact_topk(rows, queries[done:done + 1], k)
+        done += 1
+    dt = time.perf_counter() - t0
+    qps_sample = done / dt
+    # numpy/BLAS brute force on the same sample (SURVEY 8d baseline (a))
+    t1 = time.perf_counter()
+    reps = 0
+    qn = oracle.normalize_rows(queries)
+    while reps < 64 and (time.perf_counter() - t1) < 5.0:
+        s = rows @ qn[reps]
+        top = np.argpartition(-s, k)[:k]
+        top = top[np.argsort(-s[top], kind="stable")]
+        reps += 1
+    np_qps = reps / (time.perf_counter() - t1)
+    scale = sample_rows / target_rows
+    return {"value": qps_sample * scale, "unit": "queries/s", "cores": int(oracle.lib().ora_num_threads()), "kind": "port",
+            "sample": f"{done} batch-1 queries over a {sample_rows}x{dim} fp32 sample of the corpus, exact top-{k}; "
+                      f"QPS scaled by {sample_rows}/{target_rows} rows (linear scan)",
+            "numpy_sgemv_qps_scaled": np_qps * scale, "host_cpus": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--rows", type=int, default=10_000_000, help="total corpus rows (BASELINE: 10M)")
+    ap.add_argument("--dim", type=int, default=768)
+    ap.add_argument("--batch", type=int, default=1, help="queries per step (BASELINE: 1 and 1024)")
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--kprime", type=int, default=40)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--blocks-per-cu", type=int, default=0)
+    ap.add_argument("--nt", type=int, default=-1)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the engine has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    kp = args.kprime if args.dtype == "bf16" else 0
+    n, dim, b, k = args.rows, args.dim, args.batch, args.k
+    spec = SynthSpec(seed=args.seed, kind=1, n_clusters=max(1, int(np.sqrt(n))), noise=0.3)   # clustered (SURVEY 8d ii)
+    qspec = SynthSpec(seed=args.seed + 1, kind=2, noise=0.5, base_kind=1, base_seed=args.seed, base_n=n,
+                      base_n_clusters=spec.n_clusters, base_noise=0.3)
+
+    t_build = time.perf_counter()
+    sh = ShardedIndex(dim, args.dtype, True, device=device)
+    sh.add_synth_partition(n, spec)
+    lo, hi = shard_range(n, rank, world)
+    n_local = hi - lo
+    if args.blocks_per_cu:
+        sh.local.set_option("scan_blocks_per_cu", args.blocks_per_cu)
+    if args.nt >= 0:
+        sh.local.set_option("scan_nt_loads", args.nt)
+    # a pool of distinct query batches, resident in HBM
+    n_sets = 16 if b > 1 else 64
+    qpool = torch.empty((n_sets, b, dim), dtype=torch.float32, device=device)
+    for s_ in range(n_sets):
+        sh.local.synth_rows_device(qpool[s_].data_ptr(), s_ * b, b, qspec, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    t_build = time.perf_counter() - t_build
+
+    def step(i):
+        return sh.search(qpool[i % n_sets], k, kp)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    sh.local.set_option("timing_ring", max(1, min(args.steps, 65536)))
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        idx, dd = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    tstats = sh.local.timing_stats()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # sanity inside the bench: planted neighbour of the last batch is rank 1 and results ascend
+    last = (args.steps - 1) % n_sets
+    idx_h, dist_h = idx.cpu().numpy(), dd.cpu().numpy()
+    from oracle import oracle as _ora   # checker only
+    src = np.array([_ora.synth_query_src(qspec, last * b + j) for j in range(min(b, 8))])
+    planted_ok = bool(np.array_equal(idx_h[: len(src), 0], src)) and bool(np.all(np.diff(dist_h, axis=1) >= 0))
+
+    if rank == 0:
+        esz = 2 if args.dtype == "bf16" else 4
+        mfma = b >= 16 and args.dtype == "bf16"
+        scan_ms = tstats["scan_ms_sum"] / max(tstats["n"], 1)
+        if mfma:
+            alg = 2.0 * b * n_local * dim
+            roof = {"bound": "mfma", "achieved": alg / (scan_ms * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s"}
+        else:
+            alg = float(n_local) * dim * esz           # one corpus pass per launch
+            roof = {"bound": "hbm", "achieved": alg / (scan_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s"}
+        roof["frac"] = roof["achieved"] / roof["peak"]
+        roof["traffic"] = None
+        roof["kernel"] = "scan_mfma_topk_kernel" if mfma else "scan_topk_kernel"
+        roof["kernel_avg_ms"] = scan_ms
+        roof["merge_rerank_avg_ms"] = tstats["merge_ms_sum"] / max(tstats["n"], 1)
+        out = {
+            "metric": f"QPS @k={k}, {n // 1_000_000}Mx{dim} corpus, batch {b}",
+            "value": args.steps * b / elapsed, "unit": "queries/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{n}x{dim} {args.dtype} clustered synthetic corpus row-sharded over {world} GPU(s), "
+                                   f"batch {b}, exact cosine top-{k}" + (f", k'={kp} fp32 rerank" if kp else ""),
+                       "rows": n, "dim": dim, "batch": b, "k": k, "kprime": kp, "rows_per_gpu": n_local,
+                       "parallelism": f"row-shard x{world} + all-gather merge" if world > 1 else "single GPU"},
+            "roofline": roof,
+            "checks": {"planted_neighbour_first_and_ascending": planted_ok},
+            "build_s": t_build,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(dim, k, n, args.seed)
+        print(json.dumps(out), flush=True)
+    sh.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

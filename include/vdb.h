@@ -156,7 +156,13 @@ int vdb_load(vdb_t** out, const char* dir, int dtype, int keep_f32_for_rerank, i
  * (n * dim * sizeof(T) per corpus pass).  Synchronises the handle's events. */
 int vdb_last_timing(vdb_t* h, float* scan_ms, float* merge_ms, double* bytes_streamed);
 
-/* Tuning knobs: "scan_blocks_per_cu", "scan_nt_loads", "batch_mfma_min_b".
+/* Sums over the searches recorded in the timing ring (option "timing_ring" = ring
+ * capacity, default 1; at most that many most-recent searches are summed).
+ * Lets a benchmark read the scan kernel's average duration over its whole timed
+ * region without synchronising between steps.  reset != 0 restarts the count. */
+int vdb_timing_stats(vdb_t* h, int64_t* n_searches, double* scan_ms_sum, double* merge_ms_sum, int reset);
+
+/* Tuning knobs: "timing_ring", "scan_blocks_per_cu", "scan_nt_loads", "batch_mfma_min_b".
  * Unknown names return VDB_ERR_ARG. */
 int vdb_set_option(vdb_t* h, const char* name, int64_t value);
 

@@ -442,10 +442,18 @@ int vdb_last_timing(vdb_t* h, float* scan_ms, float* merge_ms, double* bytes) {
   if (bytes) *bytes = h->last_bytes;
   return VDB_OK;
 }
+int vdb_timing_stats(vdb_t* h, int64_t* n, double* a, double* b, int reset) {
+  (void)reset;
+  if (!h) return VDB_ERR_ARG;
+  if (n) *n = 0;
+  if (a) *a = 0.0;
+  if (b) *b = 0.0;
+  return VDB_OK;
+}
 int vdb_set_option(vdb_t* h, const char* name, int64_t value) {
   (void)value;
   if (!h || !name) return VDB_ERR_ARG;
-  if (!strcmp(name, "scan_blocks_per_cu") || !strcmp(name, "scan_nt_loads") || !strcmp(name, "batch_mfma_min_b")) return VDB_OK;
+  if (!strcmp(name, "timing_ring") || !strcmp(name, "scan_blocks_per_cu") || !strcmp(name, "scan_nt_loads") || !strcmp(name, "batch_mfma_min_b")) return VDB_OK;
   return fail(h, VDB_ERR_ARG, "set_option: unknown option");
 }
 

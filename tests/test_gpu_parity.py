@@ -1,0 +1,244 @@
+"""GPU suite (-m gpu): the HIP engine, called through the C ABI, against the CPU
+oracle on the same seeded inputs, the committed golden vectors, and — at sizes
+the oracle cannot scan — size-independent properties.
+
+Tolerances (BASELINE.json): scores within 1e-5 relative of the exact fp64
+cosine; id lists identical except ties inside that tolerance; bf16 + fp32
+rerank recall@10 >= 0.999.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from vectordb_amd import FlatIndex, SynthSpec
+from tests.util import check_topk, recall_at_k
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _spec(g, prefix):
+    return SynthSpec(**{f: g[f"{prefix}_{f}"].item() for f, _ in SynthSpec._fields_})
+
+
+def _qn(oracle_mod, queries):
+    return oracle_mod.normalize_rows(np.ascontiguousarray(queries, np.float32))
+
+
+@pytest.fixture(scope="module")
+def corpus20k(oracle_mod):
+    n, dim = 20011, 768  # not a multiple of any tile size
+    spec = SynthSpec(seed=1234, kind=1, n_clusters=141, noise=0.3)
+    qspec = SynthSpec(seed=99, kind=2, noise=0.5, base_kind=1, base_seed=1234, base_n=n, base_n_clusters=141, base_noise=0.3)
+    rows = oracle_mod.normalize_rows(oracle_mod.synth_rows(0, n, dim, spec))
+    queries = oracle_mod.synth_rows(0, 9, dim, qspec)
+    return n, dim, spec, rows, queries
+
+
+def test_device_generator_bit_exact(hip_lib, oracle_mod):
+    """synth rows generated in HBM == the oracle's, bit for bit (via add_synth + fetch
+    of the normalised rows, and via the raw generator into a torch buffer)."""
+    import torch
+    for spec in (SynthSpec(seed=5, kind=0), SynthSpec(seed=5, kind=1, n_clusters=7, noise=0.3),
+                 SynthSpec(seed=8, kind=2, noise=0.25, base_kind=1, base_seed=5, base_n=1000, base_n_clusters=7, base_noise=0.3)):
+        ix = FlatIndex(768, "f32")
+        buf = torch.empty((130, 768), dtype=torch.float32, device="cuda")
+        ix.synth_rows_device(buf.data_ptr(), 1000, 130, spec)
+        torch.cuda.synchronize()
+        raw = oracle_mod.synth_rows(1000, 130, 768, spec)
+        assert np.array_equal(buf.cpu().numpy(), raw)
+        ix.add_synth(1000, 130, spec)
+        got = ix.fetch(np.arange(130))
+        ref = oracle_mod.normalize_rows(raw)
+        assert np.max(np.abs(got.view(np.int32).astype(np.int64) - ref.view(np.int32).astype(np.int64))) <= 1  # <= 1 ulp
+        ix.close()
+
+
+@pytest.mark.parametrize("name", ["iso", "clustered"])
+def test_golden_synth_f32(hip_lib, oracle_mod, name):
+    g = np.load(os.path.join(GOLD, f"synth_{name}_n4096.npz"))
+    n, dim, b = int(g["n"]), int(g["dim"]), int(g["b"])
+    spec, qspec = _spec(g, "spec"), _spec(g, "qspec")
+    rows = oracle_mod.normalize_rows(oracle_mod.synth_rows(0, n, dim, spec))
+    queries = oracle_mod.synth_rows(0, b, dim, qspec)
+    ix = FlatIndex(dim, "f32")
+    ix.add_synth(0, n, spec)
+    assert ix.count() == n
+    for k in (1, 10, 30, 100):
+        idx, dist = ix.search(queries, k)
+        check_topk(idx, dist, g[f"idx_k{k}"], g[f"dist_k{k}"], g[f"score_k{k}"], rows, _qn(oracle_mod, queries), what=f"{name} k={k}")
+        # batch-1 calls (every reference call site is batch 1) give the same answer
+        i1, d1 = ix.search(queries[:1], k)
+        assert np.array_equal(i1, idx[:1]) and np.array_equal(d1, dist[:1])
+    ix.close()
+
+
+def test_golden_adversarial(hip_lib, oracle_mod):
+    """duplicates, exact ties, a zero row, a zero query, k > N; generic (non-768) dim path."""
+    g = np.load(os.path.join(GOLD, "adversarial_d64.npz"))
+    rows_n = oracle_mod.normalize_rows(g["rows"])
+    for dtype, kpf in (("f32", 0), ("bf16", 1)):
+        ix = FlatIndex(64, dtype)
+        ix.add(g["rows"])
+        for k in (1, 5, 31, 40):
+            kp = 0 if not kpf else min(max(4 * k, 32), 1024)
+            idx, dist = ix.search(g["queries"], k, kp)
+            swaps = check_topk(idx, dist, g[f"idx_k{k}"], g[f"dist_k{k}"], g[f"score_k{k}"], rows_n, _qn(oracle_mod, g["queries"]),
+                               what=f"adversarial {dtype} k={k}")
+            if dtype == "f32" and k == 1:
+                assert swaps == 0
+        ix.close()
+
+
+@pytest.mark.parametrize("dtype,kp", [("f32", 0), ("bf16", 0), ("bf16", 40)])
+def test_parity_20k(hip_lib, oracle_mod, corpus20k, dtype, kp):
+    n, dim, spec, rows, queries = corpus20k
+    ix = FlatIndex(dim, dtype)
+    ix.add_synth(0, n, spec)
+    qn = _qn(oracle_mod, queries)
+    for b in (1, 2, 3, 9):   # exercises the 1/2/4-queries-per-pass kernels
+        for k in (1, 10, 30):
+            if kp and kp < k:
+                continue
+            idx, dist = ix.search(queries[:b], k, kp)
+            if dtype == "bf16" and kp == 0:
+                # no rerank: scores are those of the bf16-rounded corpus (fp32 query)
+                rows_b = oracle_mod.round_bf16(rows)
+                r_idx, r_dist, r_sc = oracle_mod.exact_topk(rows_b, queries[:b], k)
+                check_topk(idx, dist, r_idx, r_dist, r_sc, rows_b, qn[:b], what=f"bf16 raw b={b} k={k}")
+            else:
+                r_idx, r_dist, r_sc = oracle_mod.exact_topk(rows, queries[:b], k)
+                check_topk(idx, dist, r_idx, r_dist, r_sc, rows, qn[:b], what=f"{dtype} b={b} k={k}")
+                if kp:
+                    assert recall_at_k(idx, r_idx) >= 0.999
+    ix.close()
+
+
+def test_large_k_and_host_add(hip_lib, oracle_mod):
+    """k = 100..1000 (multi-entry wave lists), rows added from host memory in two calls."""
+    rng = np.random.default_rng(3)
+    rows = rng.standard_normal((3000, 384)).astype(np.float32)
+    rows_n = oracle_mod.normalize_rows(rows)
+    queries = rows[[10, 2000]] + 0.05 * rng.standard_normal((2, 384)).astype(np.float32)
+    ix = FlatIndex(384, "f32")
+    ix.add(rows[:1234]); ix.add(rows[1234:])
+    got = ix.fetch([0, 1233, 1234, 2999])
+    ref = rows_n[[0, 1233, 1234, 2999]]
+    assert np.max(np.abs(got.view(np.int32).astype(np.int64) - ref.view(np.int32).astype(np.int64))) <= 1
+    for k in (100, 200, 500, 1000):
+        idx, dist = ix.search(queries, k)
+        r_idx, r_dist, r_sc = oracle_mod.exact_topk(rows_n, queries, k)
+        check_topk(idx, dist, r_idx, r_dist, r_sc, rows_n, _qn(oracle_mod, queries), what=f"k={k}")
+    ix.close()
+
+
+def test_empty_and_tiny_store(hip_lib):
+    ix = FlatIndex(768, "f32")
+    idx, dist = ix.search(np.ones((2, 768), np.float32), 5)
+    assert np.all(idx == -1) and np.all(np.isinf(dist))
+    ix.add(np.eye(768, dtype=np.float32)[:3])
+    idx, dist = ix.search(np.eye(768, dtype=np.float32)[1:2], 5)
+    assert idx[0].tolist() == [1, 0, 2, -1, -1]
+    assert abs(dist[0, 0]) < 1e-6 and abs(dist[0, 1] - 1) < 1e-6 and np.isinf(dist[0, 3])
+    ix.close()
+
+
+def test_selfjoin_and_self_first(hip_lib, oracle_mod, corpus20k):
+    """(i) a stored vector queried against the store returns itself first with distance ~0
+    (tests/test_vectordb.py:168-171); self-join with exclude_self equals the oracle's."""
+    n, dim, spec, rows, _ = corpus20k
+    m = 3000
+    ix = FlatIndex(dim, "f32")
+    ix.add_synth(0, m, spec)
+    idx, dist = ix.selfjoin(1, exclude_self=False, q_row0=0, q_n=200)
+    assert np.array_equal(idx[:, 0], np.arange(200)) and np.all(np.abs(dist[:, 0]) < 2e-6)
+    idx, dist = ix.selfjoin(5, exclude_self=True, q_row0=100, q_n=64)
+    assert not np.any(idx == (100 + np.arange(64))[:, None])
+    sub = rows[:m]
+    for j in (0, 63):
+        masked = sub.copy()
+        masked[100 + j] = 0  # the oracle sees the query's own row zeroed out (score 0 < neighbours')
+        r_idx, r_dist, r_sc = oracle_mod.exact_topk(masked, sub[100 + j:101 + j], 5)
+        check_topk(idx[j:j + 1], dist[j:j + 1], r_idx, r_dist, r_sc, sub, sub[100 + j:101 + j], what=f"selfjoin q{j}")
+    ix.close()
+
+
+def test_save_load_roundtrip(hip_lib, oracle_mod, tmp_path, corpus20k):
+    n, dim, spec, rows, queries = corpus20k
+    ix = FlatIndex(dim, "f32")
+    ix.add_synth(0, 5000, spec)
+    idx, dist = ix.search(queries, 10)
+    ix.save(str(tmp_path))
+    ix.close()
+    ix2 = FlatIndex.load(str(tmp_path), "f32")
+    assert ix2.count() == 5000
+    i2, d2 = ix2.search(queries, 10)
+    assert np.array_equal(idx, i2) and np.array_equal(dist, d2)
+    ix2.close()
+    ix3 = FlatIndex.load(str(tmp_path), "bf16", True)
+    i3, d3 = ix3.search(queries, 10, 40)
+    assert recall_at_k(i3, idx) >= 0.999 and np.allclose(d3, dist, atol=2e-6)
+    ix3.close()
+
+
+def test_shard_merge_equals_whole(hip_lib, oracle_mod, corpus20k):
+    """Partition property: merging the per-shard top-k (device merge kernel) equals the
+    whole-corpus answer bit for bit — results are independent of the shard count."""
+    import torch
+    n, dim, spec, rows, queries = corpus20k
+    b, k = queries.shape[0], 10
+    whole = FlatIndex(dim, "f32")
+    whole.add_synth(0, n, spec)
+    w_idx, w_dist = whole.search(queries, k)
+    whole.close()
+    for g in (2, 3, 8):
+        per = -(-n // g)
+        cd = torch.empty((g, b, k), dtype=torch.float32, device="cuda")
+        ci = torch.empty((g, b, k), dtype=torch.int64, device="cuda")
+        q_dev = torch.from_numpy(queries).cuda()
+        shards = []
+        for s in range(g):
+            lo, hi = min(n, s * per), min(n, (s + 1) * per)
+            ix = FlatIndex(dim, "f32")
+            ix.set_row_offset(lo)
+            ix.add_synth(lo, hi - lo, spec)
+            ix.search_device(q_dev.data_ptr(), b, k, 0, ci[s].data_ptr(), cd[s].data_ptr(), torch.cuda.current_stream().cuda_stream)
+            shards.append(ix)
+        out_i = torch.empty((b, k), dtype=torch.int64, device="cuda")
+        out_d = torch.empty((b, k), dtype=torch.float32, device="cuda")
+        shards[0].merge_topk_device(cd.data_ptr(), ci.data_ptr(), g, b, k, out_i.data_ptr(), out_d.data_ptr(),
+                                    torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(out_i.cpu().numpy(), w_idx), g
+        assert np.array_equal(out_d.cpu().numpy(), w_dist), g
+        for ix in shards:
+            ix.close()
+
+
+def test_million_rows_properties(hip_lib, oracle_mod):
+    """BASELINE config 2 size (1M x 768 fp32, batch 1): planted neighbour found first,
+    returned distances equal the CPU-recomputed ones for the returned rows, ascending,
+    and bf16+rerank agrees with fp32."""
+    n, dim, k = 1_000_000, 768, 10
+    spec = SynthSpec(seed=1234, kind=0)
+    qspec = SynthSpec(seed=4242, kind=2, noise=0.5, base_kind=0, base_seed=1234, base_n=n)
+    queries = oracle_mod.synth_rows(0, 4, dim, qspec)
+    qn = _qn(oracle_mod, queries)
+    ix = FlatIndex(dim, "f32")
+    ix.add_synth(0, n, spec)
+    idx, dist = ix.search(queries, k)
+    t = ix.last_timing()
+    assert t["bytes_streamed"] == n * dim * 4 * 1  # 4 queries share one corpus pass
+    ix.close()
+    for q in range(4):
+        assert idx[q, 0] == oracle_mod.synth_query_src(qspec, q)
+        got_rows = np.concatenate([oracle_mod.normalize_rows(oracle_mod.synth_rows(int(r), 1, dim, spec)) for r in idx[q]])
+        true_d = 1.0 - got_rows.astype(np.float64) @ qn[q].astype(np.float64)
+        assert np.allclose(true_d, dist[q], rtol=0, atol=1e-5 * np.abs(1 - true_d) + 2e-6)
+        assert np.all(np.diff(dist[q]) >= 0)
+    ixb = FlatIndex(dim, "bf16", True)
+    ixb.add_synth(0, n, spec)
+    ib, db = ixb.search(queries, k, 40)
+    ixb.close()
+    assert recall_at_k(ib, idx) >= 0.999 and np.allclose(db, dist, atol=2e-6)

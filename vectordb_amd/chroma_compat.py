@@ -107,9 +107,10 @@ class Collection:
         return self._index
 
     def _raw_matrix(self) -> np.ndarray:
+        if not self._raw:
+            return np.zeros((0, self._dim or 0), np.float32)
         if self._raw_cat is None or len(self._raw) > 1:
-            self._raw_cat = (np.concatenate(self._raw, axis=0) if self._raw
-                             else np.zeros((0, self._dim or 0), np.float32))
+            self._raw_cat = np.concatenate(self._raw, axis=0)
             self._raw = [self._raw_cat]
         return self._raw_cat
 

@@ -35,7 +35,9 @@ struct vdb {
   float* rows_f32 = nullptr;      // [cap][ld] normalised fp32 (dtype f32, or rerank copy)
   uint16_t* rows_bf16 = nullptr;  // [cap][ld] bf16 (dtype bf16)
   hipStream_t stream = nullptr;
-  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  std::vector<hipEvent_t> ring;   // timing ring: 3 events (start, scan end, finish) per recorded search
+  hipEvent_t* ev = nullptr;       // triple of the search in flight
+  int64_t n_timed = 0;            // searches recorded since the ring was (re)set
   bool timing_valid = false;
   double last_bytes = 0.0;
   int n_cu = 256;
@@ -226,6 +228,8 @@ int search_core(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
   const int n_rows = (int)h->n;
   const bool fast_dim = (h->ld == h->dim) && (h->dim == 768 || h->dim == 384);
 
+  h->ev = h->ring.data() + 3 * (size_t)(h->n_timed % (int64_t)(h->ring.size() / 3));
+  h->n_timed++;
   HIP_TRY(h, hipEventRecord(h->ev[0], st));
   h->last_bytes = 0.0;
 
@@ -309,6 +313,14 @@ int search_core(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
   return VDB_OK;
 }
 
+int resize_ring(vdb_t* h, int cap) {
+  for (hipEvent_t e : h->ring) if (e) (void)hipEventDestroy(e);
+  h->ring.assign((size_t)cap * 3, nullptr);
+  h->ev = nullptr; h->n_timed = 0; h->timing_valid = false;
+  for (hipEvent_t& e : h->ring) HIP_TRY(h, hipEventCreate(&e));
+  return VDB_OK;
+}
+
 int check_search_args(vdb_t* h, const void* q, int b, int k, int kp, const void* oi, const void* od) {
   if (b < 0 || (b > 0 && (!q || !oi || !od))) return fail(h, VDB_ERR_ARG, "search: NULL buffer");
   if (k < 1 || k > VDB_MAX_K) return fail(h, VDB_ERR_ARG, "search: k must be in [1,1024]");
@@ -355,8 +367,7 @@ int vdb_create(vdb_t** out, int dim, int dtype, int keep_f32, int device_id) {
     return fail(nullptr, VDB_ERR_DEVICE, "vdb_create: device initialisation failed");
   }
   h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  for (int i = 0; i < 3; ++i)
-    if (hipEventCreate(&h->ev[i]) != hipSuccess) { vdb_destroy(h); return fail(nullptr, VDB_ERR_DEVICE, "vdb_create: event creation failed"); }
+  if (resize_ring(h, 1) != VDB_OK) { vdb_destroy(h); return fail(nullptr, VDB_ERR_DEVICE, "vdb_create: event creation failed"); }
   *out = h;
   return VDB_OK;
 }
@@ -369,7 +380,7 @@ void vdb_destroy(vdb_t* h) {
   for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
   if (h->rows_f32) (void)hipFree(h->rows_f32);
   if (h->rows_bf16) (void)hipFree(h->rows_bf16);
-  for (int i = 0; i < 3; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+  for (hipEvent_t e : h->ring) if (e) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -624,9 +635,38 @@ int vdb_last_timing(vdb_t* h, float* scan_ms, float* merge_ms, double* bytes) {
   return VDB_OK;
 }
 
+int vdb_timing_stats(vdb_t* h, int64_t* n_searches, double* scan_ms_sum, double* merge_ms_sum, int reset) {
+  if (!h) return VDB_ERR_ARG;
+  int rc = set_device(h);
+  if (rc) return rc;
+  const int64_t cap = (int64_t)(h->ring.size() / 3);
+  const int64_t cnt = std::min(h->n_timed, cap);
+  double a = 0.0, b = 0.0;
+  for (int64_t i = 0; i < cnt; ++i) {
+    hipEvent_t* e = h->ring.data() + 3 * (size_t)i;
+    float x = 0.f, y = 0.f;
+    HIP_TRY(h, hipEventSynchronize(e[2]));
+    HIP_TRY(h, hipEventElapsedTime(&x, e[0], e[1]));
+    HIP_TRY(h, hipEventElapsedTime(&y, e[1], e[2]));
+    a += x; b += y;
+  }
+  if (n_searches) *n_searches = cnt;
+  if (scan_ms_sum) *scan_ms_sum = a;
+  if (merge_ms_sum) *merge_ms_sum = b;
+  if (reset) h->n_timed = 0;
+  return VDB_OK;
+}
+
 int vdb_set_option(vdb_t* h, const char* name, int64_t value) {
   if (!h || !name) return VDB_ERR_ARG;
   if (!strcmp(name, "scan_blocks_per_cu")) { if (value < 1 || value > 32) return fail(h, VDB_ERR_ARG, "scan_blocks_per_cu must be in [1,32]"); h->scan_blocks_per_cu = (int)value; return VDB_OK; }
+  if (!strcmp(name, "timing_ring")) {
+    if (value < 1 || value > 65536) return fail(h, VDB_ERR_ARG, "timing_ring must be in [1,65536]");
+    int rc = set_device(h);
+    if (rc) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return resize_ring(h, (int)value);
+  }
   if (!strcmp(name, "scan_nt_loads")) { h->scan_nt_loads = value != 0; return VDB_OK; }
   if (!strcmp(name, "batch_mfma_min_b")) { if (value < 1) return fail(h, VDB_ERR_ARG, "batch_mfma_min_b must be >= 1"); h->batch_mfma_min_b = (int)std::min<int64_t>(value, 1 << 30); return VDB_OK; }
   return fail(h, VDB_ERR_ARG, std::string("set_option: unknown option ") + name);

@@ -156,5 +156,10 @@ class FlatIndex:
         self._chk(self._lib.vdb_last_timing(self._h, C.byref(a), C.byref(b), C.byref(by)))
         return {"scan_ms": a.value, "merge_ms": b.value, "bytes_streamed": by.value}
 
+    def timing_stats(self, reset: bool = True) -> dict:
+        n, a, b = C.c_int64(), C.c_double(), C.c_double()
+        self._chk(self._lib.vdb_timing_stats(self._h, C.byref(n), C.byref(a), C.byref(b), int(reset)))
+        return {"n": int(n.value), "scan_ms_sum": a.value, "merge_ms_sum": b.value}
+
     def set_option(self, name: str, value: int) -> None:
         self._chk(self._lib.vdb_set_option(self._h, name.encode(), int(value)))
