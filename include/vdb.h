@@ -115,7 +115,9 @@ int vdb_search(vdb_t* h, const float* queries_host, int b, int k, int rerank_kpr
                int64_t* out_idx_host, float* out_dist_host);
 
 /* Same with device-resident queries and outputs, asynchronous on `stream`
- * (a hipStream_t; NULL = the handle's own stream).  The caller synchronises. */
+ * (a hipStream_t; NULL = the default (null) stream, as everywhere in HIP).  The
+ * caller synchronises.  All *_dev calls of one handle must be issued on one
+ * stream at a time (they share the handle's workspaces). */
 int vdb_search_dev(vdb_t* h, const float* queries_dev, int b, int k, int rerank_kprime,
                    int64_t* out_idx_dev, float* out_dist_dev, void* stream);
 

@@ -67,7 +67,8 @@ int fail(vdb_t* h, int code, const std::string& msg) {
 
 int ensure(vdb_t* h, DevBuf& b, size_t bytes) {
   if (bytes <= b.bytes) return VDB_OK;
-  if (b.p) { HIP_TRY(h, hipStreamSynchronize(h->stream)); HIP_TRY(h, hipFree(b.p)); b.p = nullptr; b.bytes = 0; }
+  // a workspace may still be in use on a caller's stream: drain the device before freeing it
+  if (b.p) { HIP_TRY(h, hipDeviceSynchronize()); HIP_TRY(h, hipFree(b.p)); b.p = nullptr; b.bytes = 0; }
   size_t want = std::max(bytes, (size_t)4096);
   HIP_TRY(h, hipMalloc(&b.p, want));
   b.bytes = want;
@@ -447,7 +448,7 @@ int vdb_search_dev(vdb_t* h, const float* queries_dev, int b, int k, int kp, int
   if (rc) return rc;
   if (b == 0) return VDB_OK;
   if ((rc = set_device(h))) return rc;
-  hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+  hipStream_t st = (hipStream_t)stream;  // NULL = the default (null) stream, HIP convention
   float* qn = nullptr;
   if ((rc = prep_queries(h, queries_dev, b, st, &qn))) return rc;
   return search_core(h, qn, b, k, kp, -1, out_idx_dev, out_dist_dev, st);
@@ -480,7 +481,7 @@ int vdb_merge_topk_dev(vdb_t* h, const float* cd, int64_t dstride, const int64_t
   if (b == 0) return VDB_OK;
   int rc = set_device(h);
   if (rc) return rc;
-  hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+  hipStream_t st = (hipStream_t)stream;  // NULL = the default (null) stream, HIP convention
   if (dstride < 0 || istride < 0) return fail(h, VDB_ERR_ARG, "merge: negative stride");
   hipLaunchKernelGGL(merge_shards_kernel, dim3(b), dim3(256), 0, st, cd, (long long)(dstride ? dstride : (int64_t)b * k),
                      (const long long*)ci, (long long)(istride ? istride : (int64_t)b * k), g, k, (long long*)oi, od);
@@ -678,7 +679,7 @@ int vdb_synth_rows_dev(vdb_t* h, float* out_dev, int64_t row0, int64_t n, const 
   if (n == 0) return VDB_OK;
   int rc = set_device(h);
   if (rc) return rc;
-  hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+  hipStream_t st = (hipStream_t)stream;  // NULL = the default (null) stream, HIP convention
   const int blocks = (int)std::min<int64_t>((n + 3) / 4, (int64_t)h->n_cu * 8);
   hipLaunchKernelGGL(synth_rows_kernel, dim3(blocks), dim3(256), 0, st, out_dev, (long long)row0, (long long)n, h->dim, h->dim, *spec);
   HIP_TRY(h, hipGetLastError());
