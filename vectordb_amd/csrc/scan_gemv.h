@@ -76,12 +76,17 @@ __device__ __forceinline__ void block_merge_store(WaveTopK<E> (&tk)[QB], int kk,
         if (ow == w) continue;
         const float* os = ls + (ow * QB + q) * kk;
         const int* oi = li + (ow * QB + q) * kk;
-        for (int base = 0; base < kk; base += 64) {
-          const int p = base + lane;
-          const bool valid = p < kk;
-          const float cs = valid ? os[p] : -INFINITY;
-          const int ci = valid ? oi[p] : kIdxSentinel;
-          tk[q].push_lanes(cs, ci, valid);
+        if constexpr (E == 1) {
+          const bool valid = lane < kk;   // the other wave's list is sorted: bitonic merge
+          tk[q].merge_sorted(valid ? os[lane] : -INFINITY, valid ? oi[lane] : kIdxSentinel);
+        } else {
+          for (int base = 0; base < kk; base += 64) {
+            const int p = base + lane;
+            const bool valid = p < kk;
+            const float cs = valid ? os[p] : -INFINITY;
+            const int ci = valid ? oi[p] : kIdxSentinel;
+            tk[q].push_lanes(cs, ci, valid);
+          }
         }
       }
       tk[q].store(part_s + ((size_t)q * n_parts + part) * kk, part_i + ((size_t)q * n_parts + part) * kk);

@@ -39,6 +39,48 @@ __global__ __launch_bounds__(kMergeThreads) void merge_lists_kernel(const float*
                           gridDim.x, blockIdx.x);
 }
 
+// ---- kk <= 64: every partial list is one sorted entry per lane -> bitonic folds ----
+// Fold lists [l0, l1) of one query (layout [list][kk]) into the wave's list.
+__device__ __forceinline__ void fold_sorted_lists(WaveTopK<1>& tk, const float* __restrict__ in_s,
+                                                  const int* __restrict__ in_i, int l0, int l1, int step, int kk) {
+  const int lane = lane_id();
+  const bool valid = lane < kk;
+  for (int l = l0; l < l1; l += step)
+    tk.merge_sorted(valid ? in_s[(size_t)l * kk + lane] : -INFINITY, valid ? in_i[(size_t)l * kk + lane] : kIdxSentinel);
+}
+
+// Tree-merge the NW per-wave lists of a block through LDS; wave 0 ends with the result.
+template <int NW>
+__device__ __forceinline__ void block_tree_merge(WaveTopK<1>& tk, float* ls, int* li) {
+  const int w = threadIdx.x >> 6;
+  const int lane = lane_id();
+#pragma unroll
+  for (int half = NW / 2; half >= 1; half >>= 1) {
+    if (w >= half && w < 2 * half) { ls[(w - half) * 64 + lane] = tk.s[0]; li[(w - half) * 64 + lane] = tk.id[0]; }
+    __syncthreads();
+    if (w < half) tk.merge_sorted(ls[w * 64 + lane], li[w * 64 + lane]);
+    __syncthreads();
+  }
+}
+
+// Level-1 merge: block (256 threads) folds `lists_per_block` lists; out [q][gridDim.x][kk].
+__global__ __launch_bounds__(256) void merge_sorted_lists_kernel(const float* __restrict__ in_s,
+                                                                 const int* __restrict__ in_i, int n_lists,
+                                                                 int lists_per_block, int kk,
+                                                                 float* __restrict__ out_s, int* __restrict__ out_i) {
+  __shared__ float ls[2 * 64];
+  __shared__ int li[2 * 64];
+  const int q = blockIdx.y;
+  const int w = threadIdx.x >> 6;
+  const int l0 = blockIdx.x * lists_per_block;
+  const int l1 = min(n_lists, l0 + lists_per_block);
+  WaveTopK<1> tk;
+  tk.init(kk);
+  fold_sorted_lists(tk, in_s + (size_t)q * n_lists * kk, in_i + (size_t)q * n_lists * kk, l0 + w, l1, 4, kk);
+  block_tree_merge<4>(tk, ls, li);
+  if (w == 0) tk.store(out_s + ((size_t)q * gridDim.x + blockIdx.x) * kk, out_i + ((size_t)q * gridDim.x + blockIdx.x) * kk);
+}
+
 __device__ __forceinline__ bool dist_better(float d, long long i, float od, long long oi) {
   return (d < od) || (d == od && i < oi);
 }
@@ -111,6 +153,58 @@ __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ r
     if (lane == 0) { ls[c] = tot; li[c] = id; }
   }
   __syncthreads();
+  rank_and_write(ls, li, kk, k, row_offset, out_idx + (size_t)q * k, out_dist + (size_t)q * k);
+}
+
+// kk <= 64 finish in ONE launch: fold the remaining (<= 64) sorted lists, optionally
+// re-score the kk survivors in fp32 (rerank), rank by (distance, index), write k.
+template <bool RERANK>
+__global__ __launch_bounds__(1024) void final_sorted_kernel(const float* __restrict__ in_s, const int* __restrict__ in_i,
+                                                            int n_lists, int kk, int k, long long row_offset,
+                                                            const float* __restrict__ rows_f32, int ld,
+                                                            const float* __restrict__ qn,
+                                                            long long* __restrict__ out_idx,
+                                                            float* __restrict__ out_dist) {
+  __shared__ float ls[8 * 64];
+  __shared__ int li[8 * 64];
+  const int q = blockIdx.x;
+  const int w = threadIdx.x >> 6;
+  const int lane = lane_id();
+  WaveTopK<1> tk;
+  tk.init(kk);
+  fold_sorted_lists(tk, in_s + (size_t)q * n_lists * kk, in_i + (size_t)q * n_lists * kk, w, n_lists, 16, kk);
+  block_tree_merge<16>(tk, ls, li);
+  if (w == 0) tk.store(ls, li);
+  __syncthreads();
+  if constexpr (RERANK) {
+    // each wave re-scores candidates w, w+16, w+32, w+48: all row loads in flight together
+    const f32x4* qv = reinterpret_cast<const f32x4*>(qn + (size_t)q * ld);
+    const int c4 = ld >> 2;
+    int ids[4];
+    float acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { const int c = w + 16 * t; ids[t] = c < kk ? li[c] : kIdxSentinel; acc[t] = 0.f; }
+    for (int j = lane; j < c4; j += 64) {
+      const f32x4 b = qv[j];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (ids[t] != kIdxSentinel) {  // wave-uniform
+          const f32x4 a = reinterpret_cast<const f32x4*>(rows_f32 + (size_t)ids[t] * ld)[j];
+          acc[t] = fmaf(a.x, b.x, acc[t]); acc[t] = fmaf(a.y, b.y, acc[t]);
+          acc[t] = fmaf(a.z, b.z, acc[t]); acc[t] = fmaf(a.w, b.w, acc[t]);
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int c = w + 16 * t;
+      if (ids[t] != kIdxSentinel) {
+        const float tot = wave_sum(acc[t]);
+        if (lane == 0) ls[c] = tot;
+      }
+    }
+    __syncthreads();
+  }
   rank_and_write(ls, li, kk, k, row_offset, out_idx + (size_t)q * k, out_dist + (size_t)q * k);
 }
 

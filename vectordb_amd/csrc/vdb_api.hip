@@ -196,14 +196,35 @@ void launch_merge(int e, const float* is, const int* ii, int n_cand, int cpb, in
   }
 }
 
-// Reduce [b][n_parts][kk] partial lists to [b][kk]; returns pointers to the result.
-int merge_partials(vdb_t* h, int b, int n_parts, int kk, hipStream_t st, float** res_s, int** res_i) {
+// Reduce the [b][n_parts][kk] partial lists of one query chunk to the b x k outputs:
+// hierarchical merge, then fp32 rerank (kp != 0) or plain ranking.
+int finish_search(vdb_t* h, int b, int n_parts, int kk, int k, int kp, const float* qn, int64_t* oi, float* od,
+                  hipStream_t st) {
   float* cur_s = (float*)h->w_part_s.p;
   int* cur_i = (int*)h->w_part_i.p;
   float* oth_s = (float*)h->w_part2_s.p;
   int* oth_i = (int*)h->w_part2_i.p;
   const int e = entries_for(kk);
   int lists = n_parts;
+  if (e == 1) {
+    // sorted one-entry-per-lane lists: bitonic folds, 32 lists per block, then one fused finish launch
+    while (lists > 64) {
+      const int gx = (lists + 31) / 32;
+      hipLaunchKernelGGL(merge_sorted_lists_kernel, dim3(gx, b), dim3(256), 0, st, cur_s, cur_i, lists, 32, kk, oth_s, oth_i);
+      HIP_TRY(h, hipGetLastError());
+      std::swap(cur_s, oth_s);
+      std::swap(cur_i, oth_i);
+      lists = gx;
+    }
+    if (kp)
+      hipLaunchKernelGGL((final_sorted_kernel<true>), dim3(b), dim3(1024), 0, st, cur_s, cur_i, lists, kk, k,
+                         (long long)h->row_offset, h->rows_f32, h->ld, qn, (long long*)oi, od);
+    else
+      hipLaunchKernelGGL((final_sorted_kernel<false>), dim3(b), dim3(1024), 0, st, cur_s, cur_i, lists, kk, k,
+                         (long long)h->row_offset, (const float*)nullptr, h->ld, qn, (long long*)oi, od);
+    HIP_TRY(h, hipGetLastError());
+    return VDB_OK;
+  }
   while (lists > 1) {
     const int lists_per_block = std::max(2, std::min(lists, std::max(32, 4096 / kk)));
     const int gx = (lists + lists_per_block - 1) / lists_per_block;
@@ -213,8 +234,13 @@ int merge_partials(vdb_t* h, int b, int n_parts, int kk, hipStream_t st, float**
     std::swap(cur_i, oth_i);
     lists = gx;
   }
-  *res_s = cur_s;
-  *res_i = cur_i;
+  if (kp)
+    hipLaunchKernelGGL(rerank_kernel, dim3(b), dim3(256), (size_t)kk * 8, st, h->rows_f32, h->ld, qn, cur_i, kk, k,
+                       (long long)h->row_offset, (long long*)oi, od);
+  else
+    hipLaunchKernelGGL(finalize_kernel, dim3(b), dim3(256), (size_t)kk * 8, st, cur_s, cur_i, kk, k,
+                       (long long)h->row_offset, (long long*)oi, od);
+  HIP_TRY(h, hipGetLastError());
   return VDB_OK;
 }
 
@@ -295,18 +321,8 @@ int search_core(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
     }
     if (q0 == 0 && b <= qchunk) HIP_TRY(h, hipEventRecord(h->ev[1], st));
     // --- merge + finish ----------------------------------------------------
-    float* ms; int* mi;
-    if ((rc = merge_partials(h, cb, grid, kk, st, &ms, &mi))) return rc;
-    int64_t* oi = out_idx + (size_t)q0 * k;
-    float* od = out_dist + (size_t)q0 * k;
-    if (kp) {
-      hipLaunchKernelGGL(rerank_kernel, dim3(cb), dim3(256), (size_t)kk * 8, st, h->rows_f32, h->ld,
-                         qn + (size_t)q0 * h->ld, mi, kk, k, (long long)h->row_offset, (long long*)oi, od);
-    } else {
-      hipLaunchKernelGGL(finalize_kernel, dim3(cb), dim3(256), (size_t)kk * 8, st, ms, mi, kk, k,
-                         (long long)h->row_offset, (long long*)oi, od);
-    }
-    HIP_TRY(h, hipGetLastError());
+    if ((rc = finish_search(h, cb, grid, kk, k, kp, qn + (size_t)q0 * h->ld, out_idx + (size_t)q0 * k,
+                            out_dist + (size_t)q0 * k, st))) return rc;
   }
   if (b > qchunk) HIP_TRY(h, hipEventRecord(h->ev[1], st));  // multi-chunk: scan/merge interleave, report total as scan
   HIP_TRY(h, hipEventRecord(h->ev[2], st));

@@ -108,6 +108,28 @@ struct WaveTopK {
     }
   }
 
+  // Merge another *sorted* (best first) list of <= 64 entries, one per lane
+  // (sentinels behind its end), into this one.  Bitonic: lane i keeps the better
+  // of own[i] and other[63-i] — the 64 best of the union, as a bitonic sequence —
+  // then 6 compare-exchange stages restore the order.  ~10x cheaper than 64
+  // insertions.  E == 1 only (lists of up to 64).
+  __device__ __forceinline__ void merge_sorted(float os, int oi) {
+    static_assert(E == 1, "bitonic wave merge handles one entry per lane");
+    const int lane = lane_id();
+    const float rs = __shfl(os, 63 - lane, 64);
+    const int ri = __shfl(oi, 63 - lane, 64);
+    if (cand_better(rs, ri, s[0], id[0])) { s[0] = rs; id[0] = ri; }
+#pragma unroll
+    for (int j = 32; j > 0; j >>= 1) {
+      const float ps = __shfl_xor(s[0], j, 64);
+      const int pi = __shfl_xor(id[0], j, 64);
+      const bool pb = cand_better(ps, pi, s[0], id[0]);
+      const bool lower = (lane & j) == 0;      // lower lane of the pair keeps the better one
+      if (lower ? pb : !pb) { s[0] = ps; id[0] = pi; }   // upper lane keeps the worse (lists never hold NaN)
+    }
+    refresh_thr();
+  }
+
   // Write the first kk positions to (LDS or global) arrays.
   __device__ __forceinline__ void store(float* ds, int* di) const {
     const int lane = lane_id();
