@@ -244,6 +244,46 @@ int finish_search(vdb_t* h, int b, int n_parts, int kk, int k, int kp, const flo
   return VDB_OK;
 }
 
+// Batched bf16 path: one MFMA contraction with fused top-k', then the shared finish.
+int mfma_search(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_row0, int64_t* out_idx,
+                float* out_dist, hipStream_t st) {
+  const int kk = kp ? kp : k;
+  const int n_rows = (int)h->n;
+  const int n_qt = (b + kMfBN - 1) / kMfBN;
+  const long long n_tiles = ((long long)n_rows + kMfBM - 1) / kMfBM;
+  int n_splits = (int)std::max<long long>(1, std::min<long long>(n_tiles, std::max(1, h->n_cu / n_qt)));
+  int xcd_map = 0;
+  if (n_splits >= 8) { n_splits &= ~7; xcd_map = 1; }   // n_qt blocks of a split share one XCD's L2
+  const int tiles_per_split = (int)((n_tiles + n_splits - 1) / n_splits);
+  int rc;
+  if ((rc = ensure(h, h->w_mfma, (size_t)n_qt * kMfBN * kMfDim * 2))) return rc;
+  const size_t part_elems = (size_t)b * std::max(n_splits, 1) * kk;
+  if ((rc = ensure(h, h->w_part_s, part_elems * 4))) return rc;
+  if ((rc = ensure(h, h->w_part_i, part_elems * 4))) return rc;
+  if ((rc = ensure(h, h->w_part2_s, part_elems * 4))) return rc;
+  if ((rc = ensure(h, h->w_part2_i, part_elems * 4))) return rc;
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_TRY(h, hipFuncSetAttribute((const void*)scan_mfma_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)mf_smem_bytes(kMfMaxKK)));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(queries_to_bf16_kernel, dim3(std::min(1024, (n_qt * kMfBN * kMfDim + 255) / 256)), dim3(256), 0, st,
+                     qn, b, n_qt * kMfBN, (uint16_t*)h->w_mfma.p);
+  HIP_TRY(h, hipGetLastError());
+  hipLaunchKernelGGL(scan_mfma_topk_kernel, dim3(n_qt * n_splits), dim3(kMfThreads), mf_smem_bytes(kk), st,
+                     (const unsigned char*)h->rows_bf16, n_rows, (const unsigned char*)h->w_mfma.p, b, n_qt, n_splits,
+                     tiles_per_split, kk, self_row0 >= 0 ? (int)self_row0 : -1, xcd_map, (float*)h->w_part_s.p,
+                     (int*)h->w_part_i.p);
+  HIP_TRY(h, hipGetLastError());
+  h->last_bytes = (double)n_rows * kMfDim * 2;
+  HIP_TRY(h, hipEventRecord(h->ev[1], st));
+  if ((rc = finish_search(h, b, n_splits, kk, k, kp, qn, out_idx, out_dist, st))) return rc;
+  HIP_TRY(h, hipEventRecord(h->ev[2], st));
+  h->timing_valid = true;
+  return VDB_OK;
+}
+
 // Core search over device-resident, already *normalised* queries qn [b][ld].
 // self_row0 >= 0: query q excludes row self_row0+q.
 int search_core(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_row0, int64_t* out_idx,
