@@ -314,3 +314,24 @@ def test_mfma_adversarial_order(hip_lib, oracle_mod):
     r_idx, r_dist, r_sc = oracle_mod.exact_topk(rows_n, q, 10)
     check_topk(idx, dist, r_idx, r_dist, r_sc, rows_n, _qn(oracle_mod, q), what="mfma adversarial")
     ix.close()
+
+
+def test_mfma_overflow_fallback(hip_lib, oracle_mod, corpus20k):
+    """The append path's candidate buffer overflowing (tiny capacity) or the forced-fallback
+    hook must route the batch through the exact list kernel and give the same answer."""
+    n, dim, spec, rows, _ = corpus20k
+    qspec = SynthSpec(seed=555, kind=2, noise=0.5, base_kind=1, base_seed=1234, base_n=n, base_n_clusters=141, base_noise=0.3)
+    queries = oracle_mod.synth_rows(0, 40, dim, qspec)
+    ix = FlatIndex(dim, "bf16", True)
+    ix.add_synth(0, n, spec)
+    base_idx, base_dist = ix.search(queries, 10, 40)
+    r_idx, r_dist, r_sc = oracle_mod.exact_topk(rows, queries, 10)
+    check_topk(base_idx, base_dist, r_idx, r_dist, r_sc, rows, _qn(oracle_mod, queries), what="append path")
+    ix.set_option("mfma_force_fallback", 1)
+    i1, d1 = ix.search(queries, 10, 40)
+    assert np.array_equal(i1, base_idx) and np.array_equal(d1, base_dist)
+    ix.set_option("mfma_force_fallback", 0)
+    ix.set_option("mfma_append_cap", 256)      # 256 < expected hits per query -> real overflow
+    i2, d2 = ix.search(queries, 10, 40)
+    assert np.array_equal(i2, base_idx) and np.array_equal(d2, base_dist)
+    ix.close()

@@ -45,8 +45,21 @@ __device__ __forceinline__ void fold_sorted_lists(WaveTopK<1>& tk, const float* 
                                                   const int* __restrict__ in_i, int l0, int l1, int step, int kk) {
   const int lane = lane_id();
   const bool valid = lane < kk;
-  for (int l = l0; l < l1; l += step)
-    tk.merge_sorted(valid ? in_s[(size_t)l * kk + lane] : -INFINITY, valid ? in_i[(size_t)l * kk + lane] : kIdxSentinel);
+  constexpr int kAhead = 8;  // issue the loads of up to 8 lists before the (dependent) merge chains
+  for (int l = l0; l < l1; l += kAhead * step) {
+    float cs[kAhead];
+    int ci[kAhead];
+#pragma unroll
+    for (int t = 0; t < kAhead; ++t) {
+      const int ll = l + t * step;
+      const bool ok = valid && ll < l1;
+      cs[t] = ok ? in_s[(size_t)ll * kk + lane] : -INFINITY;
+      ci[t] = ok ? in_i[(size_t)ll * kk + lane] : kIdxSentinel;
+    }
+#pragma unroll
+    for (int t = 0; t < kAhead; ++t)
+      if (l + t * step < l1) tk.merge_sorted(cs[t], ci[t]);  // wave-uniform
+  }
 }
 
 // Tree-merge the NW per-wave lists of a block through LDS; wave 0 ends with the result.
@@ -164,12 +177,16 @@ __global__ __launch_bounds__(1024) void final_sorted_kernel(const float* __restr
                                                             const float* __restrict__ rows_f32, int ld,
                                                             const float* __restrict__ qn,
                                                             long long* __restrict__ out_idx,
-                                                            float* __restrict__ out_dist) {
+                                                            float* __restrict__ out_dist,
+                                                            const int* __restrict__ alt_flag = nullptr,
+                                                            const float* __restrict__ alt_s = nullptr,
+                                                            const int* __restrict__ alt_i = nullptr, int alt_lists = 0) {
   __shared__ float ls[8 * 64];
   __shared__ int li[8 * 64];
   const int q = blockIdx.x;
   const int w = threadIdx.x >> 6;
   const int lane = lane_id();
+  if (alt_flag && *alt_flag) { in_s = alt_s; in_i = alt_i; n_lists = alt_lists; }   // block-uniform
   WaveTopK<1> tk;
   tk.init(kk);
   fold_sorted_lists(tk, in_s + (size_t)q * n_lists * kk, in_i + (size_t)q * n_lists * kk, w, n_lists, 16, kk);

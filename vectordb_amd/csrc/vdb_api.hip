@@ -14,7 +14,7 @@
 #include "scan_gemv.h"
 #include "select.h"
 #include "synth.h"
-#include "scan_mfma.h"
+#include "scan_mfma3.h"
 
 using namespace vdbk;
 
@@ -45,8 +45,12 @@ struct vdb {
   int scan_blocks_per_cu = 4;
   int scan_nt_loads = 1;
   int batch_mfma_min_b = 16;
+  int mfma_ablate = 0;   // diagnostic: skip parts of the MFMA kernel (wrong results, timing only)
   // workspaces (grown on demand)
   DevBuf w_q, w_part_s, w_part_i, w_part2_s, w_part2_i, w_stage, w_out_i, w_out_d, w_idx, w_mfma;
+  DevBuf w_cand_s, w_cand_i, w_cand_cnt, w_thr, w_dense, w_list_s, w_list_i;   // append-path state
+  int mfma_append_cap = 16384;   // candidate buffer entries per query
+  int mfma_force_fallback = 0;   // test hook: route through the exact list kernel
   std::string err;
 };
 
@@ -84,6 +88,7 @@ int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 int grow(vdb_t* h, int64_t want_rows) {
   if (want_rows <= h->cap) return VDB_OK;
+  want_rows = (want_rows + 255) / 256 * 256;   // the MFMA kernel reads whole 256-row tiles (tail rows are masked)
   const size_t ld = (size_t)h->ld;
   if (h->keep_f32) {
     float* p = nullptr;
@@ -244,41 +249,114 @@ int finish_search(vdb_t* h, int b, int n_parts, int kk, int k, int kp, const flo
   return VDB_OK;
 }
 
-// Batched bf16 path: one MFMA contraction with fused top-k', then the shared finish.
+// Batched bf16 path (scan_mfma3.h): dense sample -> thresholds -> append passes over
+// growing strided samples -> full pass -> exact top-k' lists; exact list kernel
+// (scan_mfma.h) as the device-flagged overflow fallback; then the shared fp32 finish.
+struct MfGrid { int n_splits, xcd_map, tiles_per_split; };
+MfGrid mf_grid(int n_cu, int n_qt, long long pass_tiles, int max_splits) {
+  MfGrid g;
+  g.n_splits = (int)std::max<long long>(1, std::min<long long>(pass_tiles, std::max(1, std::min(max_splits, n_cu / n_qt))));
+  g.xcd_map = 0;
+  if (g.n_splits >= 8) { g.n_splits &= ~7; g.xcd_map = 1; }   // the n_qt blocks of a split share one XCD's L2
+  g.tiles_per_split = (int)((pass_tiles + g.n_splits - 1) / g.n_splits);
+  return g;
+}
+
 int mfma_search(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_row0, int64_t* out_idx,
                 float* out_dist, hipStream_t st) {
   const int kk = kp ? kp : k;
   const int n_rows = (int)h->n;
   const int n_qt = (b + kMfBN - 1) / kMfBN;
   const long long n_tiles = ((long long)n_rows + kMfBM - 1) / kMfBM;
-  int n_splits = (int)std::max<long long>(1, std::min<long long>(n_tiles, std::max(1, h->n_cu / n_qt)));
-  int xcd_map = 0;
-  if (n_splits >= 8) { n_splits &= ~7; xcd_map = 1; }   // n_qt blocks of a split share one XCD's L2
-  const int tiles_per_split = (int)((n_tiles + n_splits - 1) / n_splits);
+  const int cap = h->mfma_append_cap;
+  const int self0 = self_row0 >= 0 ? (int)self_row0 : -1;
+  const unsigned char* rows = (const unsigned char*)h->rows_bf16;
   int rc;
   if ((rc = ensure(h, h->w_mfma, (size_t)n_qt * kMfBN * kMfDim * 2))) return rc;
-  const size_t part_elems = (size_t)b * std::max(n_splits, 1) * kk;
+  if ((rc = ensure(h, h->w_cand_s, (size_t)b * cap * 4))) return rc;
+  if ((rc = ensure(h, h->w_cand_i, (size_t)b * cap * 4))) return rc;
+  if ((rc = ensure(h, h->w_cand_cnt, (size_t)(b + 16) * 4))) return rc;   // [b] counters + overflow flag at [b]
+  if ((rc = ensure(h, h->w_thr, (size_t)b * 4))) return rc;
+  if ((rc = ensure(h, h->w_dense, (size_t)b * kMf3DenseLd * 4))) return rc;
+  if ((rc = ensure(h, h->w_list_s, (size_t)b * kk * 4))) return rc;
+  if ((rc = ensure(h, h->w_list_i, (size_t)b * kk * 4))) return rc;
+  const MfGrid fb = mf_grid(h->n_cu, n_qt, n_tiles, 64);   // fallback grid (<= 64 partial lists per query)
+  const size_t part_elems = (size_t)b * fb.n_splits * kk;
   if ((rc = ensure(h, h->w_part_s, part_elems * 4))) return rc;
   if ((rc = ensure(h, h->w_part_i, part_elems * 4))) return rc;
-  if ((rc = ensure(h, h->w_part2_s, part_elems * 4))) return rc;
-  if ((rc = ensure(h, h->w_part2_i, part_elems * 4))) return rc;
   static bool attr_set = false;
   if (!attr_set) {
-    HIP_TRY(h, hipFuncSetAttribute((const void*)scan_mfma_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)mf_smem_bytes(kMfMaxKK)));
+    HIP_TRY(h, hipFuncSetAttribute((const void*)scan_mfma_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_smem_bytes()));
+    HIP_TRY(h, hipFuncSetAttribute((const void*)scan_mfma_pass_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kMfNumStages * kMfStage));
+    HIP_TRY(h, hipFuncSetAttribute((const void*)scan_mfma_pass_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kMfNumStages * kMfStage));
     attr_set = true;
   }
+  const unsigned char* qb16 = (const unsigned char*)h->w_mfma.p;
+  float* cand_s = (float*)h->w_cand_s.p;
+  int* cand_i = (int*)h->w_cand_i.p;
+  int* cand_cnt = (int*)h->w_cand_cnt.p;
+  int* ovf = cand_cnt + b;
+  float* thr = (float*)h->w_thr.p;
+  float* dense = (float*)h->w_dense.p;
+  float* list_s = (float*)h->w_list_s.p;
+  int* list_i = (int*)h->w_list_i.p;
+  const size_t smem3 = (size_t)kMfNumStages * kMfStage;
+
   hipLaunchKernelGGL(queries_to_bf16_kernel, dim3(std::min(1024, (n_qt * kMfBN * kMfDim + 255) / 256)), dim3(256), 0, st,
                      qn, b, n_qt * kMfBN, (uint16_t*)h->w_mfma.p);
   HIP_TRY(h, hipGetLastError());
-  hipLaunchKernelGGL(scan_mfma_topk_kernel, dim3(n_qt * n_splits), dim3(kMfThreads), mf_smem_bytes(kk), st,
-                     (const unsigned char*)h->rows_bf16, n_rows, (const unsigned char*)h->w_mfma.p, b, n_qt, n_splits,
-                     tiles_per_split, kk, self_row0 >= 0 ? (int)self_row0 : -1, xcd_map, (float*)h->w_part_s.p,
-                     (int*)h->w_part_i.p);
+  HIP_TRY(h, hipMemsetAsync(ovf, 0, 4, st));
+  h->last_bytes = 0.0;
+
+  // pass 0: dense scores of a strided 4-tile sample -> t0 = k'-th best per query
+  long long t_cur = std::min<long long>(n_tiles, kMf3DenseTiles);
+  {
+    const int stride = (int)std::max<long long>(1, n_tiles / t_cur);
+    const MfGrid g = mf_grid(h->n_cu, n_qt, t_cur, 1 << 30);
+    hipLaunchKernelGGL((scan_mfma_pass_kernel<0>), dim3(n_qt * g.n_splits), dim3(kMfThreads), smem3, st, rows, n_rows, qb16, b,
+                       n_qt, g.n_splits, g.tiles_per_split, (int)t_cur, stride, self0, g.xcd_map, (const float*)nullptr, dense,
+                       (int*)nullptr, (float*)nullptr, (int*)nullptr, 0);
+    HIP_TRY(h, hipGetLastError());
+    // rows of the dense matrix beyond the sampled tiles were never written: select over t_cur*256 columns only
+    hipLaunchKernelGGL(select_kth_dense_kernel, dim3(b), dim3(1024), 0, st, dense, kMf3DenseLd, (int)t_cur * kMfBM, kk, thr);
+    HIP_TRY(h, hipGetLastError());
+  }
+  // append passes: sample grows by R per pass so that ~cap/4 candidates are expected per query
+  const long long R = std::max<long long>(2, cap / (4LL * kk));
+  bool last = false;
+  while (!last) {
+    long long t_next = t_cur * R;
+    int stride = 1;
+    if (t_next >= n_tiles) { t_next = n_tiles; last = true; }
+    else stride = (int)(n_tiles / t_next);
+    HIP_TRY(h, hipMemsetAsync(cand_cnt, 0, (size_t)b * 4, st));
+    const MfGrid g = mf_grid(h->n_cu, n_qt, t_next, 1 << 30);
+    hipLaunchKernelGGL((scan_mfma_pass_kernel<1>), dim3(n_qt * g.n_splits), dim3(kMfThreads), smem3, st, rows, n_rows, qb16, b,
+                       n_qt, g.n_splits, g.tiles_per_split, (int)t_next, stride, self0, g.xcd_map, (const float*)thr, dense,
+                       cand_cnt, cand_s, cand_i, cap);
+    HIP_TRY(h, hipGetLastError());
+    if (last) h->last_bytes = (double)n_rows * kMfDim * 2;
+    hipLaunchKernelGGL(select_kth_kernel, dim3(b), dim3(1024), 0, st, (const float*)cand_s, (const int*)cand_i,
+                       (const int*)cand_cnt, cap, kk, thr, last ? list_s : (float*)nullptr, last ? list_i : (int*)nullptr, ovf);
+    HIP_TRY(h, hipGetLastError());
+    t_cur = t_next;
+  }
+  if (h->mfma_force_fallback) HIP_TRY(h, hipMemsetAsync(ovf, 1, 1, st));
+  // exact list kernel: returns at once unless the overflow flag is set
+  hipLaunchKernelGGL(scan_mfma_topk_kernel, dim3(n_qt * fb.n_splits), dim3(kMfThreads), mf_smem_bytes(), st, rows, n_rows, qb16, b,
+                     n_qt, fb.n_splits, fb.tiles_per_split, kk, self0, fb.xcd_map, h->mfma_ablate, (const int*)ovf,
+                     (float*)h->w_part_s.p, (int*)h->w_part_i.p);
   HIP_TRY(h, hipGetLastError());
-  h->last_bytes = (double)n_rows * kMfDim * 2;
   HIP_TRY(h, hipEventRecord(h->ev[1], st));
-  if ((rc = finish_search(h, b, n_splits, kk, k, kp, qn, out_idx, out_dist, st))) return rc;
+  if (kp)
+    hipLaunchKernelGGL((final_sorted_kernel<true>), dim3(b), dim3(1024), 0, st, (const float*)list_s, (const int*)list_i, 1, kk, k,
+                       (long long)h->row_offset, (const float*)h->rows_f32, h->ld, qn, (long long*)out_idx, out_dist,
+                       (const int*)ovf, (const float*)h->w_part_s.p, (const int*)h->w_part_i.p, fb.n_splits);
+  else
+    hipLaunchKernelGGL((final_sorted_kernel<false>), dim3(b), dim3(1024), 0, st, (const float*)list_s, (const int*)list_i, 1, kk, k,
+                       (long long)h->row_offset, (const float*)nullptr, h->ld, qn, (long long*)out_idx, out_dist,
+                       (const int*)ovf, (const float*)h->w_part_s.p, (const int*)h->w_part_i.p, fb.n_splits);
+  HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipEventRecord(h->ev[2], st));
   h->timing_valid = true;
   return VDB_OK;
@@ -311,7 +389,7 @@ int search_core(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
   }
 
   // MFMA batched path (bf16 store, fast dim, enough queries)
-  if (bf16 && h->dim == 768 && h->ld == 768 && b >= h->batch_mfma_min_b && mfma_path_supported(kk)) {
+  if (bf16 && h->dim == 768 && h->ld == 768 && b >= h->batch_mfma_min_b && mfma_path_supported(kk) && n_rows >= 4096) {
     int rc = mfma_search(h, qn, b, k, kp, self_row0, out_idx, out_dist, st);
     return rc;
   }
@@ -433,7 +511,8 @@ void vdb_destroy(vdb_t* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  DevBuf* bufs[] = {&h->w_q, &h->w_part_s, &h->w_part_i, &h->w_part2_s, &h->w_part2_i, &h->w_stage, &h->w_out_i, &h->w_out_d, &h->w_idx, &h->w_mfma};
+  DevBuf* bufs[] = {&h->w_q, &h->w_part_s, &h->w_part_i, &h->w_part2_s, &h->w_part2_i, &h->w_stage, &h->w_out_i, &h->w_out_d, &h->w_idx, &h->w_mfma,
+                    &h->w_cand_s, &h->w_cand_i, &h->w_cand_cnt, &h->w_thr, &h->w_dense, &h->w_list_s, &h->w_list_i};
   for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
   if (h->rows_f32) (void)hipFree(h->rows_f32);
   if (h->rows_bf16) (void)hipFree(h->rows_bf16);
@@ -725,6 +804,12 @@ int vdb_set_option(vdb_t* h, const char* name, int64_t value) {
     return resize_ring(h, (int)value);
   }
   if (!strcmp(name, "scan_nt_loads")) { h->scan_nt_loads = value != 0; return VDB_OK; }
+  if (!strcmp(name, "mfma_ablate")) { h->mfma_ablate = (int)value; return VDB_OK; }
+  if (!strcmp(name, "mfma_force_fallback")) { h->mfma_force_fallback = value != 0; return VDB_OK; }
+  if (!strcmp(name, "mfma_append_cap")) {
+    if (value < 256 || value > (1 << 22)) return fail(h, VDB_ERR_ARG, "mfma_append_cap must be in [256, 4194304]");
+    h->mfma_append_cap = (int)value; return VDB_OK;
+  }
   if (!strcmp(name, "batch_mfma_min_b")) { if (value < 1) return fail(h, VDB_ERR_ARG, "batch_mfma_min_b must be >= 1"); h->batch_mfma_min_b = (int)std::min<int64_t>(value, 1 << 30); return VDB_OK; }
   return fail(h, VDB_ERR_ARG, std::string("set_option: unknown option ") + name);
 }
