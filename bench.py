@@ -164,7 +164,17 @@ def main():
             alg = float(n_local) * dim * esz           # one corpus pass per launch
             roof = {"bound": "hbm", "achieved": alg / (scan_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s"}
         roof["frac"] = roof["achieved"] / roof["peak"]
+        # HBM bytes per launch from a separate rocprofv3 --pmc FETCH_SIZE pass of this same command
+        # (profiles/r01_pmc_traffic.json; gfx950 FETCH_SIZE correction applied there)
         roof["traffic"] = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                t = json.load(f)["workloads"].get(f"{n}x{dim} {args.dtype} batch {b}")
+            if t and world == 1:
+                roof["traffic"] = t["traffic_bytes"]
+                roof["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, separate pass)"
+        except (OSError, KeyError, ValueError):
+            pass
         roof["kernel"] = "scan_mfma_topk_kernel" if mfma else "scan_topk_kernel"
         roof["kernel_avg_ms"] = scan_ms
         roof["merge_rerank_avg_ms"] = tstats["merge_ms_sum"] / max(tstats["n"], 1)

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(kMfThreads) void scan_mfma_pass_kernel(
   extern __shared__ __align__(16) unsigned char smem[];   // the only LDS object: 3 stages
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int w = tid >> 6;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: keeps the wave-role branches and the staging cursor in SGPRs
   const int wm = w >> 1, wn = w & 1;
   const int hsel = lane >> 5;
 
@@ -67,6 +67,9 @@ __global__ __launch_bounds__(kMfThreads) void scan_mfma_pass_kernel(
     thr[0] = thr_in[min(q0, b - 1)];
     thr[1] = thr_in[min(q0 + 32, b - 1)];
   }
+  // retire the threshold loads here: a first use inside the loop would make hipcc wait vmcnt(0)
+  // (draining the two staged tiles in flight) at every tile's epilogue
+  asm volatile("" :: "v"(thr[0]), "v"(thr[1]));
 
   // per-thread constant offsets: staging sources (bytes inside a tile) and fragment reads
   unsigned a_off[4], b_off[2];
@@ -91,7 +94,7 @@ __global__ __launch_bounds__(kMfThreads) void scan_mfma_pass_kernel(
     fb0[s] = kMfStageA + br0 * 128 + ((c ^ ((br0 >> 1) & 7)) << 4);
     fb1[s] = kMfStageA + br1 * 128 + ((c ^ ((br1 >> 1) & 7)) << 4);
   }
-  const int wbase16 = (tid >> 6) * 1024;                       // this wave's 1 KiB slot inside a piece
+  const int wbase16 = w * 1024;                       // this wave's 1 KiB slot inside a piece
   const unsigned char* qblk = qb16 + (size_t)qbase * kMfRowBytes;
 
   // staging cursor (scalar): next (tile, k-step) to issue
