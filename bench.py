@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--nt", type=int, default=-1)
+    ap.add_argument("--clusters", type=int, default=0, help="synthetic clusters (default sqrt(rows))")
     ap.add_argument("--ablate", type=int, default=0, help="diagnostic: MFMA kernel ablation bits (results invalid)")
     args = ap.parse_args()
 
@@ -99,7 +100,7 @@ def main():
 
     kp = args.kprime if args.dtype == "bf16" else 0
     n, dim, b, k = args.rows, args.dim, args.batch, args.k
-    spec = SynthSpec(seed=args.seed, kind=1, n_clusters=max(1, int(np.sqrt(n))), noise=0.3)   # clustered (SURVEY 8d ii)
+    spec = SynthSpec(seed=args.seed, kind=1, n_clusters=args.clusters or max(1, int(np.sqrt(n))), noise=0.3)   # clustered (SURVEY 8d ii)
     qspec = SynthSpec(seed=args.seed + 1, kind=2, noise=0.5, base_kind=1, base_seed=args.seed, base_n=n,
                       base_n_clusters=spec.n_clusters, base_noise=0.3)
 
@@ -188,7 +189,9 @@ def main():
                        "rows": n, "dim": dim, "batch": b, "k": k, "kprime": kp, "rows_per_gpu": n_local,
                        "parallelism": f"row-shard x{world} + all-gather merge" if world > 1 else "single GPU"},
             "roofline": roof,
-            "checks": {"planted_neighbour_first_and_ascending": planted_ok},
+            "checks": {"planted_neighbour_first_and_ascending": planted_ok,
+                       "mfma_overflow_fallback": sh.local.get_stat("mfma_last_overflow"),
+                       "mfma_hits_per_query": sh.local.get_stat("mfma_last_hits") / b},
             "build_s": t_build,
         }
         if world == 1 and not args.no_cpu_baseline:

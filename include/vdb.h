@@ -168,6 +168,11 @@ int vdb_timing_stats(vdb_t* h, int64_t* n_searches, double* scan_ms_sum, double*
  * Unknown names return VDB_ERR_ARG. */
 int vdb_set_option(vdb_t* h, const char* name, int64_t value);
 
+/* Read-only counters/diagnostics (synchronises the device): "mfma_last_overflow" (1 when the
+ * last batched search overflowed its candidate buffers and ran the exact list kernel),
+ * "rows", "capacity_rows".  Unknown names return VDB_ERR_ARG. */
+int vdb_get_stat(vdb_t* h, const char* name, int64_t* value);
+
 /* ---- synthetic data (bench/test utility; no reference counterpart) ----- */
 
 /* Write raw (un-normalised) synthetic rows [row0,row0+n) into out_dev

@@ -442,6 +442,13 @@ int vdb_last_timing(vdb_t* h, float* scan_ms, float* merge_ms, double* bytes) {
   if (bytes) *bytes = h->last_bytes;
   return VDB_OK;
 }
+int vdb_get_stat(vdb_t* h, const char* name, int64_t* value) {
+  if (!h || !name || !value) return VDB_ERR_ARG;
+  if (!strcmp(name, "rows")) { *value = h->n; return VDB_OK; }
+  if (!strcmp(name, "capacity_rows")) { *value = h->cap; return VDB_OK; }
+  if (!strcmp(name, "mfma_last_overflow") || !strcmp(name, "mfma_last_hits")) { *value = 0; return VDB_OK; }
+  return fail(h, VDB_ERR_ARG, "get_stat: unknown stat");
+}
 int vdb_timing_stats(vdb_t* h, int64_t* n, double* a, double* b, int reset) {
   (void)reset;
   if (!h) return VDB_ERR_ARG;

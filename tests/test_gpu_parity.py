@@ -335,3 +335,43 @@ def test_mfma_overflow_fallback(hip_lib, oracle_mod, corpus20k):
     i2, d2 = ix.search(queries, 10, 40)
     assert np.array_equal(i2, base_idx) and np.array_equal(d2, base_dist)
     ix.close()
+
+
+def test_packed_allgather_layout_merge(hip_lib, oracle_mod, corpus20k):
+    """What ShardedIndex does on N GPUs, on one: every shard's packed [idx int64 | dist f32]
+    result laid out back to back as all_gather_into_tensor would, merged in place with
+    shard strides; plus the world-size-1 ShardedIndex path on the device."""
+    import torch
+    from vectordb_amd.distributed import ShardedIndex
+    n, dim, spec, rows, queries = corpus20k
+    b, k, g = queries.shape[0], 10, 4
+    words = b * k + (b * k + 1) // 2
+    gathered = torch.zeros(g * words, dtype=torch.int64, device="cuda")
+    q_dev = torch.from_numpy(queries).cuda()
+    per = -(-n // g)
+    st = torch.cuda.current_stream().cuda_stream
+    shards = []
+    for s in range(g):
+        lo, hi = min(n, s * per), min(n, (s + 1) * per)
+        ix = FlatIndex(dim, "bf16", True)
+        ix.set_row_offset(lo)
+        ix.add_synth(lo, hi - lo, spec)
+        base = gathered.data_ptr() + 8 * s * words
+        ix.search_device(q_dev.data_ptr(), b, k, 40, base, base + 8 * b * k, st)
+        shards.append(ix)
+    out_i = torch.empty((b, k), dtype=torch.int64, device="cuda")
+    out_d = torch.empty((b, k), dtype=torch.float32, device="cuda")
+    shards[0].merge_topk_device(gathered.data_ptr() + 8 * b * k, gathered.data_ptr(), g, b, k, out_i.data_ptr(), out_d.data_ptr(),
+                                st, dist_shard_stride=2 * words, idx_shard_stride=words)
+    torch.cuda.synchronize()
+    for ix in shards:
+        ix.close()
+    sh = ShardedIndex(dim, "bf16", True, device=torch.device("cuda", 0))
+    sh.add_synth_partition(n, spec)
+    w_idx, w_dist = sh.search(q_dev, k, 40)
+    torch.cuda.synchronize()
+    assert np.array_equal(out_i.cpu().numpy(), w_idx.cpu().numpy())
+    assert np.array_equal(out_d.cpu().numpy(), w_dist.cpu().numpy())
+    r_idx, r_dist, r_sc = oracle_mod.exact_topk(rows, queries, k)
+    check_topk(w_idx.cpu().numpy(), w_dist.cpu().numpy(), r_idx, r_dist, r_sc, rows, _qn(oracle_mod, queries), what="sharded world=1")
+    sh.close()

@@ -23,7 +23,7 @@ VDB_MAX_K = 1024
 SYMBOLS = (
     "vdb_create", "vdb_destroy", "vdb_last_error", "vdb_reserve", "vdb_set_row_offset",
     "vdb_add", "vdb_add_dev", "vdb_count", "vdb_search", "vdb_search_dev", "vdb_merge_topk_dev",
-    "vdb_selfjoin", "vdb_fetch", "vdb_save", "vdb_load", "vdb_last_timing", "vdb_timing_stats", "vdb_set_option",
+    "vdb_selfjoin", "vdb_fetch", "vdb_save", "vdb_load", "vdb_last_timing", "vdb_timing_stats", "vdb_set_option", "vdb_get_stat",
     "vdb_synth_rows_dev", "vdb_add_synth",
 )
 
@@ -68,6 +68,7 @@ def _declare(lib: C.CDLL) -> C.CDLL:
     lib.vdb_load.argtypes = [C.POINTER(vp), C.c_char_p, i32, i32, i32]
     lib.vdb_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_double)]
     lib.vdb_timing_stats.argtypes = [vp, C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(C.c_double), i32]
+    lib.vdb_get_stat.argtypes = [vp, C.c_char_p, C.POINTER(i64)]
     lib.vdb_set_option.argtypes = [vp, C.c_char_p, i64]
     lib.vdb_synth_rows_dev.argtypes = [vp, pf, i64, i64, C.POINTER(SynthSpec), vp]
     lib.vdb_add_synth.argtypes = [vp, i64, i64, C.POINTER(SynthSpec)]

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <sys/stat.h>
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -50,6 +51,7 @@ struct vdb {
   DevBuf w_q, w_part_s, w_part_i, w_part2_s, w_part2_i, w_stage, w_out_i, w_out_d, w_idx, w_mfma;
   DevBuf w_cand_s, w_cand_i, w_cand_cnt, w_thr, w_dense, w_list_s, w_list_i;   // append-path state
   int mfma_append_cap = 16384;   // candidate buffer entries per query
+  int mfma_last_b = 0;           // batch size of the last MFMA search (locates its overflow flag)
   int mfma_force_fallback = 0;   // test hook: route through the exact list kernel
   std::string err;
 };
@@ -296,6 +298,7 @@ int mfma_search(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
   int* cand_i = (int*)h->w_cand_i.p;
   int* cand_cnt = (int*)h->w_cand_cnt.p;
   int* ovf = cand_cnt + b;
+  h->mfma_last_b = b;
   float* thr = (float*)h->w_thr.p;
   float* dense = (float*)h->w_dense.p;
   float* list_s = (float*)h->w_list_s.p;
@@ -321,14 +324,16 @@ int mfma_search(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
     hipLaunchKernelGGL(select_kth_dense_kernel, dim3(b), dim3(1024), 0, st, dense, kMf3DenseLd, (int)t_cur * kMfBM, kk, thr);
     HIP_TRY(h, hipGetLastError());
   }
-  // append passes: sample grows by R per pass so that ~cap/4 candidates are expected per query
-  const long long R = std::max<long long>(2, cap / (4LL * kk));
-  bool last = false;
-  while (!last) {
-    long long t_next = t_cur * R;
-    int stride = 1;
-    if (t_next >= n_tiles) { t_next = n_tiles; last = true; }
-    else stride = (int)(n_tiles / t_next);
+  // append passes over geometrically growing strided samples; the growth factor per pass is
+  // at most R = cap/(4 k') so that ~cap/4 candidates per query are expected in each
+  const double Rmax = std::max<double>(2.0, (double)cap / (4.0 * kk));
+  const double span = (double)n_tiles / (double)t_cur;
+  const int n_pass = span <= 1.0 ? 1 : std::max(1, (int)std::ceil(std::log(span) / std::log(Rmax) - 0.15));   // up to ~2x Rmax per pass
+  const double growth = std::pow(span, 1.0 / n_pass);
+  for (int pass = 1; pass <= n_pass; ++pass) {
+    const bool last = pass == n_pass;
+    long long t_next = last ? n_tiles : std::min<long long>(n_tiles, (long long)std::ceil((double)t_cur * growth));
+    const int stride = last ? 1 : (int)std::max<long long>(1, n_tiles / t_next);
     HIP_TRY(h, hipMemsetAsync(cand_cnt, 0, (size_t)b * 4, st));
     const MfGrid g = mf_grid(h->n_cu, n_qt, t_next, 1 << 30);
     hipLaunchKernelGGL((scan_mfma_pass_kernel<1>), dim3(n_qt * g.n_splits), dim3(kMfThreads), smem3, st, rows, n_rows, qb16, b,
@@ -812,6 +817,37 @@ int vdb_set_option(vdb_t* h, const char* name, int64_t value) {
   }
   if (!strcmp(name, "batch_mfma_min_b")) { if (value < 1) return fail(h, VDB_ERR_ARG, "batch_mfma_min_b must be >= 1"); h->batch_mfma_min_b = (int)std::min<int64_t>(value, 1 << 30); return VDB_OK; }
   return fail(h, VDB_ERR_ARG, std::string("set_option: unknown option ") + name);
+}
+
+int vdb_get_stat(vdb_t* h, const char* name, int64_t* value) {
+  if (!h || !name || !value) return VDB_ERR_ARG;
+  if (!strcmp(name, "rows")) { *value = h->n; return VDB_OK; }
+  if (!strcmp(name, "capacity_rows")) { *value = h->cap; return VDB_OK; }
+  if (!strcmp(name, "mfma_last_overflow")) {
+    *value = 0;
+    if (!h->w_cand_cnt.p || h->mfma_last_b <= 0) return VDB_OK;
+    int rc = set_device(h);
+    if (rc) return rc;
+    int flag = 0;
+    HIP_TRY(h, hipDeviceSynchronize());
+    HIP_TRY(h, hipMemcpy(&flag, (int*)h->w_cand_cnt.p + h->mfma_last_b, 4, hipMemcpyDeviceToHost));
+    *value = flag != 0;
+    return VDB_OK;
+  }
+  if (!strcmp(name, "mfma_last_hits")) {   // candidates appended by the last (full) pass, summed over queries
+    *value = 0;
+    if (!h->w_cand_cnt.p || h->mfma_last_b <= 0) return VDB_OK;
+    int rc = set_device(h);
+    if (rc) return rc;
+    std::vector<int> cnt((size_t)h->mfma_last_b);
+    HIP_TRY(h, hipDeviceSynchronize());
+    HIP_TRY(h, hipMemcpy(cnt.data(), h->w_cand_cnt.p, cnt.size() * 4, hipMemcpyDeviceToHost));
+    int64_t tot = 0;
+    for (int c : cnt) tot += c;
+    *value = tot;
+    return VDB_OK;
+  }
+  return fail(h, VDB_ERR_ARG, std::string("get_stat: unknown stat ") + name);
 }
 
 int vdb_synth_rows_dev(vdb_t* h, float* out_dev, int64_t row0, int64_t n, const vdb_synth_spec* spec, void* stream) {

@@ -161,5 +161,10 @@ class FlatIndex:
         self._chk(self._lib.vdb_timing_stats(self._h, C.byref(n), C.byref(a), C.byref(b), int(reset)))
         return {"n": int(n.value), "scan_ms_sum": a.value, "merge_ms_sum": b.value}
 
+    def get_stat(self, name: str) -> int:
+        v = C.c_int64()
+        self._chk(self._lib.vdb_get_stat(self._h, name.encode(), C.byref(v)))
+        return int(v.value)
+
     def set_option(self, name: str, value: int) -> None:
         self._chk(self._lib.vdb_set_option(self._h, name.encode(), int(value)))
