@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--nt", type=int, default=-1)
+    ap.add_argument("--mfma-variant", type=int, default=0)
     ap.add_argument("--clusters", type=int, default=0, help="synthetic clusters (default sqrt(rows))")
     ap.add_argument("--ablate", type=int, default=0, help="diagnostic: MFMA kernel ablation bits (results invalid)")
     args = ap.parse_args()
@@ -111,6 +112,8 @@ def main():
     n_local = hi - lo
     if args.blocks_per_cu:
         sh.local.set_option("scan_blocks_per_cu", args.blocks_per_cu)
+    if args.mfma_variant:
+        sh.local.set_option("mfma_variant", args.mfma_variant)
     if args.ablate:
         sh.local.set_option("mfma_ablate", args.ablate)
     if args.nt >= 0:

@@ -141,6 +141,9 @@ __global__ __launch_bounds__(kMfThreads) void scan_mfma_pass_kernel(
       a1[s] = *reinterpret_cast<const bf16x8_t*>(sb + fa1[s]);
       b1[s] = *reinterpret_cast<const bf16x8_t*>(sb + fb1[s]);
     }
+    // pin the schedule: all 16 fragment reads are in flight before the first MFMA (hipcc otherwise
+    // re-serialises them into 4 x [4 reads, wait, 4 MFMAs] on one register set, exposing LDS latency)
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[s], b0[s], acc[0][0], 0, 0, 0);

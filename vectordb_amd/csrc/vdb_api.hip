@@ -15,7 +15,7 @@
 #include "scan_gemv.h"
 #include "select.h"
 #include "synth.h"
-#include "scan_mfma3.h"
+#include "scan_mfma4.h"
 
 using namespace vdbk;
 
@@ -51,6 +51,7 @@ struct vdb {
   DevBuf w_q, w_part_s, w_part_i, w_part2_s, w_part2_i, w_stage, w_out_i, w_out_d, w_idx, w_mfma;
   DevBuf w_cand_s, w_cand_i, w_cand_cnt, w_thr, w_dense, w_list_s, w_list_i;   // append-path state
   int mfma_append_cap = 16384;   // candidate buffer entries per query
+  int mfma_variant = 4;          // 3 = barrier ring (scan_mfma3.h), 4 = warp-specialised (scan_mfma4.h)
   int mfma_last_b = 0;           // batch size of the last MFMA search (locates its overflow flag)
   int mfma_force_fallback = 0;   // test hook: route through the exact list kernel
   std::string err;
@@ -291,6 +292,8 @@ int mfma_search(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
     HIP_TRY(h, hipFuncSetAttribute((const void*)scan_mfma_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_smem_bytes()));
     HIP_TRY(h, hipFuncSetAttribute((const void*)scan_mfma_pass_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kMfNumStages * kMfStage));
     HIP_TRY(h, hipFuncSetAttribute((const void*)scan_mfma_pass_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kMfNumStages * kMfStage));
+    HIP_TRY(h, hipFuncSetAttribute((const void*)scan_mfma_ws_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_smem_bytes()));
+    HIP_TRY(h, hipFuncSetAttribute((const void*)scan_mfma_ws_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_smem_bytes()));
     attr_set = true;
   }
   const unsigned char* qb16 = (const unsigned char*)h->w_mfma.p;
@@ -316,9 +319,14 @@ int mfma_search(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
   {
     const int stride = (int)std::max<long long>(1, n_tiles / t_cur);
     const MfGrid g = mf_grid(h->n_cu, n_qt, t_cur, 1 << 30);
-    hipLaunchKernelGGL((scan_mfma_pass_kernel<0>), dim3(n_qt * g.n_splits), dim3(kMfThreads), smem3, st, rows, n_rows, qb16, b,
-                       n_qt, g.n_splits, g.tiles_per_split, (int)t_cur, stride, self0, g.xcd_map, (const float*)nullptr, dense,
-                       (int*)nullptr, (float*)nullptr, (int*)nullptr, 0);
+    if (h->mfma_variant == 4)
+      hipLaunchKernelGGL((scan_mfma_ws_kernel<0>), dim3(n_qt * g.n_splits), dim3(kWsThreads), ws_smem_bytes(), st, rows, n_rows, qb16, b,
+                         n_qt, g.n_splits, g.tiles_per_split, (int)t_cur, stride, self0, g.xcd_map, (const float*)nullptr, dense,
+                         (int*)nullptr, (float*)nullptr, (int*)nullptr, 0, ovf, 0);
+    else
+      hipLaunchKernelGGL((scan_mfma_pass_kernel<0>), dim3(n_qt * g.n_splits), dim3(kMfThreads), smem3, st, rows, n_rows, qb16, b,
+                         n_qt, g.n_splits, g.tiles_per_split, (int)t_cur, stride, self0, g.xcd_map, (const float*)nullptr, dense,
+                         (int*)nullptr, (float*)nullptr, (int*)nullptr, 0);
     HIP_TRY(h, hipGetLastError());
     // rows of the dense matrix beyond the sampled tiles were never written: select over t_cur*256 columns only
     hipLaunchKernelGGL(select_kth_dense_kernel, dim3(b), dim3(1024), 0, st, dense, kMf3DenseLd, (int)t_cur * kMfBM, kk, thr);
@@ -336,9 +344,14 @@ int mfma_search(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
     const int stride = last ? 1 : (int)std::max<long long>(1, n_tiles / t_next);
     HIP_TRY(h, hipMemsetAsync(cand_cnt, 0, (size_t)b * 4, st));
     const MfGrid g = mf_grid(h->n_cu, n_qt, t_next, 1 << 30);
-    hipLaunchKernelGGL((scan_mfma_pass_kernel<1>), dim3(n_qt * g.n_splits), dim3(kMfThreads), smem3, st, rows, n_rows, qb16, b,
-                       n_qt, g.n_splits, g.tiles_per_split, (int)t_next, stride, self0, g.xcd_map, (const float*)thr, dense,
-                       cand_cnt, cand_s, cand_i, cap);
+    if (h->mfma_variant == 4)
+      hipLaunchKernelGGL((scan_mfma_ws_kernel<1>), dim3(n_qt * g.n_splits), dim3(kWsThreads), ws_smem_bytes(), st, rows, n_rows, qb16, b,
+                         n_qt, g.n_splits, g.tiles_per_split, (int)t_next, stride, self0, g.xcd_map, (const float*)thr, dense,
+                         cand_cnt, cand_s, cand_i, cap, ovf, h->mfma_ablate);
+    else
+      hipLaunchKernelGGL((scan_mfma_pass_kernel<1>), dim3(n_qt * g.n_splits), dim3(kMfThreads), smem3, st, rows, n_rows, qb16, b,
+                         n_qt, g.n_splits, g.tiles_per_split, (int)t_next, stride, self0, g.xcd_map, (const float*)thr, dense,
+                         cand_cnt, cand_s, cand_i, cap);
     HIP_TRY(h, hipGetLastError());
     if (last) h->last_bytes = (double)n_rows * kMfDim * 2;
     hipLaunchKernelGGL(select_kth_kernel, dim3(b), dim3(1024), 0, st, (const float*)cand_s, (const int*)cand_i,
@@ -810,6 +823,10 @@ int vdb_set_option(vdb_t* h, const char* name, int64_t value) {
   }
   if (!strcmp(name, "scan_nt_loads")) { h->scan_nt_loads = value != 0; return VDB_OK; }
   if (!strcmp(name, "mfma_ablate")) { h->mfma_ablate = (int)value; return VDB_OK; }
+  if (!strcmp(name, "mfma_variant")) {
+    if (value != 3 && value != 4) return fail(h, VDB_ERR_ARG, "mfma_variant must be 3 or 4");
+    h->mfma_variant = (int)value; return VDB_OK;
+  }
   if (!strcmp(name, "mfma_force_fallback")) { h->mfma_force_fallback = value != 0; return VDB_OK; }
   if (!strcmp(name, "mfma_append_cap")) {
     if (value < 256 || value > (1 << 22)) return fail(h, VDB_ERR_ARG, "mfma_append_cap must be in [256, 4194304]");
