@@ -1,0 +1,108 @@
+"""GPU suite (-m gpu): the reference-shaped host face (ProductVectorDB, Collection,
+the batched analysis harnesses) running on the HIP engine through the C ABI,
+checked against the same calls served by the CPU oracle library."""
+import numpy as np
+import pandas as pd
+import pytest
+
+from vectordb_amd import analysis, config
+from vectordb_amd.matching import find_similar_products_bidirectional
+from vectordb_amd.vectordb import ProductVectorDB, normalize_mapping_id
+
+pytestmark = pytest.mark.gpu
+
+SPECIES = ["beef", "pork", "lamb", "veal", "chicken", "turkey", "bison", "goat"]
+CUTS = ["ribeye", "brisket", "chuck roll", "tenderloin", "short ribs", "sirloin", "flank", "shank", "round", "plate",
+        "loin", "shoulder", "rack", "breast", "thigh", "wing"]
+STYLE = ["boneless", "bone in", "trimmed", "untrimmed", "frozen", "fresh", "ground", "diced"]
+USDA = ["beef ribeye boneless", "pork shoulder bone in", "lamb rack trimmed", "chicken breast boneless fresh",
+        "turkey thigh frozen", "veal shank", "beef brisket trimmed choice", "ground beef 80", "bison sirloin",
+        "goat shoulder diced", "pork loin boneless", "chicken wing frozen", "beef short ribs bone in", "lamb shank fresh",
+        "beef tenderloin trimmed", "pork plate", "turkey breast boneless", "veal loin trimmed", "beef flank", "beef round ground"]
+
+
+def _catalogue(n):
+    rows = []
+    for i in range(n):
+        rows.append((f"{SPECIES[i % 8]} {CUTS[(i // 8) % 16]} {STYLE[(i // 128) % 8]} lot {i} grade {i % 5}", str(200000 + 3 * i)))
+    return rows
+
+
+@pytest.fixture(scope="module")
+def twin_dbs(tmp_path_factory, hip_lib, oracle_lib):
+    """The same 4 500-product catalogue (768-d hashed embeddings, bf16 storage + fp32
+    rerank) behind the HIP library and behind the oracle library."""
+    cat = _catalogue(4500)
+    uniq = pd.DataFrame(cat, columns=["product_description", "product_code"])
+    map_rows = [[USDA[i % len(USDA)], code] + [None] * 4 for i, (_, code) in enumerate(cat) if i % 9 == 0]
+    mapping_df = pd.DataFrame(map_rows, columns=["USDA_Code"] + config.GROUND_TRUTH_ID_COLS)
+    lookup = {normalize_mapping_id(r[1]): r[0] for r in map_rows}
+    for col in config.GROUND_TRUTH_ID_COLS:
+        mapping_df[col] = mapping_df[col].astype(str)
+    tx = pd.DataFrame({"ProductCode": [c for _, c in cat], "ProductDescription": [d.upper() for d, _ in cat]})
+    dbs = []
+    for name, lib in (("hip", hip_lib), ("ora", oracle_lib)):
+        db = ProductVectorDB(persist_directory=str(tmp_path_factory.mktemp(name)), embedding_model_name="hash",
+                             usda_lookup_map=lookup, dtype="bf16", lib=lib)
+        db.add_products_to_db(uniq.copy(), recreate=True)
+        dbs.append(db)
+    return dbs[0], dbs[1], uniq, mapping_df, tx
+
+
+def test_classification_harness_hip_equals_oracle(twin_dbs):
+    hip, ora, _, mapping_df, tx = twin_dbs
+    thr = 0.30
+    out_h = analysis.evaluate_usda_classification(hip, mapping_df, tx, similarity_threshold=thr, max_results=10)
+    out_o = analysis.evaluate_usda_classification(ora, mapping_df, tx, similarity_threshold=thr, max_results=10)
+    assert hip.collection._index.get_stat("mfma_last_hits") > 0          # 20 queries, k'=40, 4 500 bf16 rows: the MFMA path served it
+    dh, do = out_h[3], out_o[3]
+    kh = set(zip(dh["usda_code"], dh["product_id"]))
+    ko = set(zip(do["usda_code"], do["product_id"]))
+    # rows may differ only where the similarity sits on the threshold or ties at the cut (1e-5 relative, BASELINE tolerance)
+    for frame, other in ((dh, ko), (do, kh)):
+        extra = frame[[k not in other for k in zip(frame["usda_code"], frame["product_id"])]]
+        if len(extra):
+            cut = frame.groupby("usda_code")["similarity"].transform("min")
+            assert np.all((np.abs(extra["similarity"] - thr) < 1e-5) | (np.abs(extra["similarity"] - cut[extra.index]) < 1e-5))
+    assert len(kh & ko) >= 0.999 * len(ko) and len(ko) > 50
+    m = dh.merge(do, on=["usda_code", "product_id"], suffixes=("_h", "_o"))
+    assert np.allclose(m["similarity_h"], m["similarity_o"], rtol=1e-5, atol=2e-6)
+    assert abs(out_h[0] - out_o[0]) < 5e-3 and abs(out_h[1] - out_o[1]) < 5e-3
+
+
+def test_bidirectional_harness_hip_equals_oracle_and_sequential(twin_dbs):
+    hip, ora, uniq, _, _ = twin_dbs
+    queries = uniq.iloc[::9].head(64)                                    # all have a USDA ground truth
+    kw = dict(forward_threshold=0.5, backward_threshold=0.5, n_final_results=5)
+    ph, rh, fh, dh = analysis.test_bidirectional_similarity(hip, queries, **kw)
+    po, ro, fo, do = analysis.test_bidirectional_similarity(ora, queries, **kw)
+    assert len(dh) == len(do) and len(dh) >= 64
+    same = (dh["candidate_description"].fillna("") == do["candidate_description"].fillna(""))
+    # hashed embeddings of a templated catalogue tie often ('lot 40' vs 'lot 80' share the same features with the
+    # query); a swapped candidate must then carry the same similarities at its position (1e-5 relative, BASELINE tolerance)
+    assert same.mean() >= 0.9
+    for col in ("forward_similarity", "backward_similarity"):
+        assert np.allclose(dh[col].astype(float), do[col].astype(float), rtol=1e-5, atol=2e-6, equal_nan=True)
+    assert abs(ph - po) < 2e-2 and abs(rh - ro) < 2e-2
+    # the batched form equals the reference's one-query-at-a-time form on the same engine
+    for _, q in queries.head(8).iterrows():
+        seq = find_similar_products_bidirectional(q["product_description"], hip, n_results_initial=config.N_RESULTS_INITIAL_SEARCH,
+                                                  n_results_final=5, similarity_threshold_forward=0.5,
+                                                  similarity_threshold_backward=0.5, embedder=hip.embedder)
+        got = dh[dh["query_description"] == q["product_description"]]
+        assert [m["candidate_description"] for m in seq] == [c for c in got["candidate_description"] if c is not None]
+
+
+def test_best_match_harness_hip_equals_oracle(twin_dbs):
+    hip, ora, _, mapping_df, tx = twin_dbs
+    codes = analysis.get_unique_usda_codes(mapping_df)
+    emb = {c: hip.embedder.embed_query(c) for c in codes}
+    p2u = analysis.create_product_to_usda_mapping(tx, mapping_df)
+    sub = tx.iloc[:1500]
+    bh = analysis.generate_best_usda_matches(hip, mapping_df, sub, emb, p2u)
+    bo = analysis.generate_best_usda_matches(ora, mapping_df, sub, emb, p2u)
+    assert len(bh) == len(bo) == 1500
+    agree = (bh["best_matching_usda_code"] == bo["best_matching_usda_code"])
+    assert agree.mean() >= 0.999
+    assert np.allclose(bh["similarity_score"][agree], bo["similarity_score"][agree], rtol=1e-5, atol=2e-6)
+    assert analysis.summarize_best_matches(bh)["known"] == analysis.summarize_best_matches(bo)["known"] > 0

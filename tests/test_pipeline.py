@@ -1,0 +1,249 @@
+"""CPU suite for the rows either side of the hot path:
+the transaction pipeline + workbook reader, and the batched analysis harnesses
+checked against the reference's sequential one-query-at-a-time form.  The engine
+behind the collection is the CPU oracle library, injected explicitly (tests only)."""
+import numpy as np
+import pandas as pd
+import pytest
+
+from tests.util import write_xlsx
+from vectordb_amd import analysis, config, data_processing as dp
+from vectordb_amd.abbreviation_translator import expand_abbreviations, expand_abbreviations_in_dataframe, get_abbreviation_map
+from vectordb_amd.matching import find_best_usda_match, find_similar_products_bidirectional
+from vectordb_amd.vectordb import ProductVectorDB, build_usda_lookup, create_product_vector_db
+
+HEADER = ["ProductSK", "ProductDescription", "ProductCode", "SalesPrice"]
+ROWS = [
+    [1, "Beef  Ribeye Stk Bnls ", "51040948", 12.5],
+    [2, "beef ribeye stk bnls", "7777", 11.0],             # same cleaned text: first code wins
+    [3, "Pork Shld Bn-in", 2002, 4.25],                    # numeric code cell
+    [4, None, "3003", 1.0],                                 # dropped: no description
+    [5, "Ground Beef 80/20", None, 3.0],                    # dropped: no code
+    [6, "   ", "4004", 2.0],                                # dropped: empty after cleaning
+    [7, "Chicken Breast Bnls Sknd", "6000-2", 5.5],
+    [8, "Ground Beef 73%", "1230", 2.75],
+    [9, "Ground Beef 73% fine", "9161010", 2.8],
+]
+MAP_HEADER = ["USDA_Code", "Fulton_code", "Pritzlaff_code", "Queen_code", "Moesle_code", "Anmar_code"]
+MAP_ROWS = [
+    ["Ground beef 73%", "1040948", 90750, "1230", None, "9161010"],
+    ["112A Ribeye boneless", "7777-1", None, None, None, None],
+    ["Chicken breast", "6000", None, None, None, None],
+    [None, "5555", None, None, None, None],                # no USDA code: ignored
+]
+
+
+@pytest.fixture()
+def project(tmp_path, monkeypatch):
+    actual = tmp_path / "data" / "Actuals"
+    actual.mkdir(parents=True)
+    write_xlsx(actual / "Transaction_Report_Actual.xlsx", HEADER, ROWS, inline_from_col=3)
+    write_xlsx(actual / "Corrected_mapping.xlsx", MAP_HEADER, MAP_ROWS)
+    monkeypatch.setattr(config, "TRANSACTION_REPORT_FILE", actual / "Transaction_Report_Actual.xlsx")
+    monkeypatch.setattr(config, "GROUND_TRUTH_FILE", actual / "Corrected_mapping.xlsx")
+    monkeypatch.setattr(config, "CHROMA_DB_PATH", tmp_path / "chroma_db_actuals")
+    return tmp_path
+
+
+def test_abbreviations_case_sensitive_whole_word_longest_first():
+    m = get_abbreviation_map()
+    assert len(m) == 37 and m["Bnls"] == "Boneless" and m["Tri Tip"] == "Triangle Tip"
+    assert expand_abbreviations("Beef Rst-Rdy Bnls") == "Beef Roast-Ready Boneless"      # 'Rst-Rdy' before 'Rst'
+    assert expand_abbreviations("Rst Rnd Stk") == "Roast Round Steak"
+    assert expand_abbreviations("Tender") == "Tenderloin" and expand_abbreviations("Tenderloin") == "Tenderloin"
+    assert expand_abbreviations("Stkhouse xStk") == "Stkhouse xStk"                       # whole words only
+    assert expand_abbreviations("beef stk bnls") == "beef stk bnls"                       # case-sensitive
+    assert expand_abbreviations("") == "" and expand_abbreviations(None) is None and expand_abbreviations(7) == 7
+    df = expand_abbreviations_in_dataframe(pd.DataFrame({"a": ["Grnd Beef"], "b": ["Grnd"]}), ["a", "zzz"])
+    assert df["a"][0] == "Ground Beef" and df["b"][0] == "Grnd"
+
+
+def test_read_excel_types_and_blanks(project):
+    df = dp.read_excel(config.TRANSACTION_REPORT_FILE, sheet_name="Sheet1")
+    assert list(df.columns) == HEADER and len(df) == len(ROWS)
+    assert df["ProductSK"].dtype == np.int64 and df["SalesPrice"].dtype == np.float64
+    assert df["ProductCode"].dtype == object and df["ProductCode"][2] == 2002 and df["ProductCode"][0] == "51040948"
+    assert pd.isna(df["ProductDescription"][3]) and pd.isna(df["ProductCode"][4])
+    assert df["ProductDescription"][0] == "Beef  Ribeye Stk Bnls "          # whitespace preserved by the reader
+    assert dp.read_excel(config.TRANSACTION_REPORT_FILE).equals(df)          # default = first sheet
+    with pytest.raises(ValueError):
+        dp.read_excel(config.TRANSACTION_REPORT_FILE, sheet_name="Nope")
+    m = dp.read_excel(config.GROUND_TRUTH_FILE, sheet_name="Sheet1")
+    assert m["Pritzlaff_code"].dtype == np.float64 and m["Pritzlaff_code"][0] == 90750.0   # ints with blanks -> float, as pandas
+    assert m["Moesle_code"].isna().all()
+
+
+def test_process_transaction_data(project, capsys):
+    raw = dp.load_transaction_data()
+    out = dp.process_transaction_data(raw)
+    assert list(out.columns) == ["product_description", "product_code"]
+    # lower-cased BEFORE expansion, so nothing expands (reference data_processing.py:63); sorted by description
+    assert out["product_description"].tolist() == ["beef ribeye stk bnls", "chicken breast bnls sknd", "ground beef 73%",
+                                                    "ground beef 73% fine", "pork shld bn-in"]
+    assert out["product_code"].tolist() == ["51040948", "6000-2", "1230", "9161010", "2002"]
+    assert dp.process_transaction_data(None) is None
+    assert dp.process_transaction_data(pd.DataFrame({"x": [1]})) is None
+    assert dp.load_transaction_data(file_path=project / "missing.xlsx") is None
+    assert "not found" in capsys.readouterr().out
+    assert dp.clean_text("  A \t B\n") == "a b" and dp.clean_text(3.5) == 3.5
+
+
+def test_build_usda_lookup_from_workbook(project):
+    lk = build_usda_lookup()
+    # ids normalised: '-<n>' suffix and a leading digit of an all-digit id dropped; float cells stringified
+    assert lk["040948"] == "Ground beef 73%" and lk["230"] == "Ground beef 73%" and lk["161010"] == "Ground beef 73%"
+    assert lk["90750.0"] == "Ground beef 73%"
+    assert lk["777"] == "112A Ribeye boneless" and lk["000"] == "Chicken breast"
+    assert "555" not in lk
+    assert build_usda_lookup(mapping_file=project / "nope.xlsx") == {}
+
+
+def _db(project, oracle_lib, dtype="f32"):
+    db, uniq = create_product_vector_db(recreate=True, embedding_model_name="hash", lib=oracle_lib, dtype=dtype)
+    return db, uniq
+
+
+def test_create_product_vector_db_on_workbooks(project, oracle_lib):
+    db, uniq = _db(project, oracle_lib)
+    assert db.collection.count() == 5 == len(uniq)
+    meta = db.collection.get(ids=["item_0", "item_2"], include=["metadatas"])["metadatas"]
+    # '51040948' normalises to '1040948' while the mapping id '1040948' normalises to '040948': no match, as upstream
+    assert meta[0] == {"product_description": "beef ribeye stk bnls", "product_code": "51040948", "usda_code": "NOT_FOUND"}
+    assert meta[1]["usda_code"] == "Ground beef 73%"
+    assert db.collection.get(ids=["item_1"], include=["metadatas"])["metadatas"][0]["usda_code"] == "Chicken breast"
+    res = db.get_similar_products("ground beef 73%", n_results=2)
+    assert res.iloc[0]["product_description"] == "ground beef 73%" and res.iloc[0]["forward_similarity"] > 0.999
+    # recreate=False reopens the persisted rows instead of adding them twice
+    db2, _ = create_product_vector_db(recreate=False, embedding_model_name="hash", lib=oracle_lib)
+    assert db2.collection.count() == 5
+
+
+# ------------------------------------------------------------------ batched harnesses vs the sequential form
+def _catalogue(n=60):
+    cuts = ["ribeye", "brisket", "chuck roll", "tenderloin", "short ribs", "sirloin", "flank", "shank", "round", "plate"]
+    species = ["beef", "pork", "lamb", "veal", "chicken", "turkey"]
+    rows = []
+    for i in range(n):
+        rows.append((f"{species[i % 6]} {cuts[i % 10]} {'boneless' if i % 3 else 'bone in'} grade {i % 4}", str(100000 + 7 * i)))
+    return rows
+
+
+@pytest.fixture()
+def harness_db(tmp_path, oracle_lib):
+    cat = _catalogue()
+    usda_names = ["beef ribeye boneless", "pork brisket", "lamb chuck roll", "chicken tenderloin boneless"]
+    # mapping: product i belongs to USDA name (i % 6) when that exists
+    lookup = {}
+    map_rows = []
+    for i, (_, code) in enumerate(cat):
+        if i % 6 < len(usda_names) and i % 5 != 0:
+            map_rows.append([usda_names[i % 6], code, None, None, None, None])
+    mapping_df = pd.DataFrame(map_rows, columns=MAP_HEADER)
+    from vectordb_amd.vectordb import normalize_mapping_id
+    for r in map_rows:
+        lookup[normalize_mapping_id(r[1])] = r[0]
+    db = ProductVectorDB(persist_directory=str(tmp_path / "s"), embedding_model_name="hash", usda_lookup_map=lookup, lib=oracle_lib)
+    uniq = pd.DataFrame(cat, columns=["product_description", "product_code"])
+    db.add_products_to_db(uniq.copy(), recreate=True)
+    for col in config.GROUND_TRUTH_ID_COLS:
+        mapping_df[col] = mapping_df[col].astype(str)
+    # transactions: every product twice + two (code, description) variants + a numeric small code that collides with item_<row>
+    tx = pd.DataFrame({"ProductCode": [c for _, c in cat] * 2 + ["100000", "3"],
+                       "ProductDescription": [d.upper() for d, _ in cat] * 2 + ["BEEF RIBEYE SPECIAL", "colliding id"]})
+    return db, uniq, mapping_df, tx
+
+
+def test_usda_classification_batched_equals_sequential(harness_db):
+    db, _, mapping_df, tx = harness_db
+    thr = 0.35
+    p, r, f, detailed, per_code = analysis.evaluate_usda_classification(db, mapping_df, tx, similarity_threshold=thr, max_results=25)
+    # sequential form: analysis/run_bidirectional_test.py:202-257, one query per USDA code
+    gt = analysis.create_ground_truth_dict(mapping_df, tx)
+    assert sum(len(v) for v in gt.values()) == len(mapping_df)
+    tp = fp = fn = 0
+    seq = []
+    for usda, truth in gt.items():
+        matched = analysis.classify_products_by_usda_code(db, usda, usda, thr, max_results=25)
+        pred = {str(m["product_code"]) for m in matched}
+        tp, fp, fn = tp + len(truth & pred), fp + len(pred - truth), fn + len(truth - pred)
+        seq += [(m["usda_code"], m["product_id"], m["similarity"]) for m in matched]
+    assert tp > 0 and fp > 0                                  # the case exercises both outcomes
+    assert p == tp / (tp + fp) and r == tp / (tp + fn) and f == pytest.approx(2 * p * r / (p + r))
+    assert [(a, b) for a, b, _ in seq] == list(zip(detailed["usda_code"], detailed["product_id"]))
+    assert np.allclose([s for _, _, s in seq], detailed["similarity"], rtol=0, atol=1e-6)
+    assert list(per_code.columns) == ["usda_code", "description", "n_true_products", "n_predicted", "true_positives",
+                                      "false_positives", "false_negatives", "precision", "recall", "f1"]
+    assert list(detailed.columns) == ["product_id", "product_code", "product_description", "similarity", "usda_code", "is_correct"]
+    assert per_code["true_positives"].sum() == tp
+    empty = analysis.evaluate_usda_classification(db, mapping_df.iloc[:0], tx)
+    assert empty[:3] == (0.0, 0.0, 0.0) and empty[3].empty
+
+
+def test_bidirectional_evaluation_batched_equals_sequential(harness_db):
+    db, uniq, _, _ = harness_db
+    p, r, f, df = analysis.test_bidirectional_similarity(db, uniq, forward_threshold=0.3, backward_threshold=0.3, n_final_results=4)
+    # sequential form: analysis/bidirectional_similarity.py:246-321
+    tp = pred = actual = 0
+    rows = []
+    for _, q in uniq.iterrows():
+        usda = db._get_usda_code(q["product_code"])
+        if usda == "NOT_FOUND":
+            continue
+        actual += 1
+        ms = find_similar_products_bidirectional(q["product_description"], db, n_results_initial=config.N_RESULTS_INITIAL_SEARCH,
+                                                 n_results_final=4, similarity_threshold_forward=0.3,
+                                                 similarity_threshold_backward=0.3, embedder=db.embedder)
+        pred += len(ms)
+        if not ms:
+            rows.append((q["product_description"], None, False))
+        for m in ms:
+            ok = m["metadata"]["usda_code"] == usda
+            tp += ok
+            rows.append((q["product_description"], m["metadata"]["product_description"], ok))
+    assert actual > 0 and pred > 0 and 0 < tp < pred
+    assert (p, r) == (tp / pred, tp / actual) and f == pytest.approx(2 * p * r / (p + r))
+    got = [(a, None if pd.isna(b) else b, bool(c)) for a, b, c in zip(df["query_description"], df["candidate_description"], df["is_correct_match"])]
+    assert got == rows
+    assert list(df.columns) == ["query_description", "query_code", "true_usda_code", "candidate_description", "candidate_code",
+                                "candidate_usda_code", "forward_similarity", "backward_similarity", "is_correct_match"]
+    assert analysis.test_bidirectional_similarity(db, uniq.iloc[:0])[:3] == (0.0, 0.0, 0.0)
+    assert analysis.test_bidirectional_similarity(db, pd.DataFrame({"x": [1]}))[3].empty
+
+
+def test_best_usda_matches_batched_equals_sequential(harness_db):
+    db, _, mapping_df, tx = harness_db
+    codes = analysis.get_unique_usda_codes(mapping_df)
+    usda_emb = {c: db.embedder.embed_query(c) for c in codes}
+    p2u = analysis.create_product_to_usda_mapping(tx, mapping_df)
+    out = analysis.generate_best_usda_matches(db, mapping_df, tx, usda_emb, p2u)
+    # header of the reference's recorded output, analysis_results/best_usda_matches.csv:1
+    assert list(out.columns) == ["product_id", "product_code", "product_description", "best_matching_usda_code",
+                                 "similarity_score", "known_usda_code", "is_correct_match"]
+    uniq_pairs = tx.drop_duplicates(subset=["ProductCode", "ProductDescription"])
+    assert len(out) == len(uniq_pairs) - 1                     # code '3' collides with id item_3: dropped, as recorded upstream
+    assert "3" not in set(out["product_code"])
+    # sequential form: generate_best_usda_matches.py:177-286 (fallback branch: nearest stored vector, then the arg-max loop)
+    for _, row in out.iterrows():
+        q = db.embedder.embed_query(row["product_description"])
+        res = db.collection.query(query_embeddings=[q.tolist()], n_results=1, include=["embeddings"])
+        code, sim = find_best_usda_match(np.asarray(res["embeddings"][0][0]), usda_emb)
+        assert row["product_id"] == res["ids"][0]
+        assert code == row["best_matching_usda_code"] and abs(sim - row["similarity_score"]) < 1e-6
+        known = p2u.get(row["product_code"])
+        assert (row["known_usda_code"] == known) if known else pd.isna(row["known_usda_code"])
+        assert row["is_correct_match"] == (known == code) if known else row["is_correct_match"] is None
+    stats = analysis.summarize_best_matches(out)
+    assert stats["known"] == out["known_usda_code"].notna().sum() and stats["correct"] + stats["incorrect"] == stats["known"]
+    assert 0 < stats["correct"]
+    used = analysis.generate_best_usda_matches(db, mapping_df, tx, usda_emb, p2u, on_id_hit="use")
+    assert len(used) == len(uniq_pairs) and used[used["product_code"] == "3"]["product_id"].iloc[0] == "item_3"
+
+
+def test_reference_mapping_accuracy(harness_db):
+    db, uniq, _, _ = harness_db
+    ref_map = {"Beef Ribeye": ["beef ribeye bone in grade 2", "beef ribeye bone in grade 0", "not in the data at all"],
+               "Lonely": ["pork brisket boneless grade 1"]}
+    m = analysis.evaluate_vector_db_accuracy(db, ref_map, uniq, n_results=3)
+    assert m["total_queries"] == 2 and m["correct_matches"] + m["false_negatives"] == 2
+    assert m["correct_matches"] + m["false_positives"] == 6
+    assert 0 <= m["precision"] <= 1 and 0 <= m["f1_score"] <= 1

@@ -49,3 +49,68 @@ def recall_at_k(idx, ref_idx):
         hits += len(ref & set(int(i) for i in idx[q]))
         total += len(ref)
     return hits / max(total, 1)
+
+
+def write_xlsx(path, header, rows, sheet_name="Sheet1", inline_from_col=None):
+    """Minimal workbook writer for fixtures: str cells as shared strings (or inline
+    strings from column `inline_from_col` on), int/float as numbers, bool as 'b',
+    None as an absent cell."""
+    import zipfile
+    from xml.sax.saxutils import escape
+
+    shared, shared_ix = [], {}
+
+    def col_name(j):
+        s = ""
+        j += 1
+        while j:
+            j, r = divmod(j - 1, 26)
+            s = chr(65 + r) + s
+        return s
+
+    def cell(ref, j, v):
+        if v is None:
+            return ""
+        if isinstance(v, bool):
+            return f'<c r="{ref}" t="b"><v>{int(v)}</v></c>'
+        if isinstance(v, (int, float)):
+            return f'<c r="{ref}"><v>{v!r}</v></c>'
+        if inline_from_col is not None and j >= inline_from_col:
+            return f'<c r="{ref}" t="inlineStr"><is><t xml:space="preserve">{escape(v)}</t></is></c>'
+        if v not in shared_ix:
+            shared_ix[v] = len(shared)
+            shared.append(v)
+        return f'<c r="{ref}" t="s"><v>{shared_ix[v]}</v></c>'
+
+    ns = 'xmlns="http://schemas.openxmlformats.org/spreadsheetml/2006/main"'
+    body = []
+    for i, r in enumerate([list(header)] + [list(r) for r in rows]):
+        cells = "".join(cell(f"{col_name(j)}{i + 1}", j, v) for j, v in enumerate(r))
+        if cells:
+            body.append(f'<row r="{i + 1}">{cells}</row>')
+    sheet = f'<?xml version="1.0" encoding="UTF-8"?><worksheet {ns}><sheetData>{"".join(body)}</sheetData></worksheet>'
+    sst = (f'<?xml version="1.0" encoding="UTF-8"?><sst {ns} count="{len(shared)}" uniqueCount="{len(shared)}">'
+           + "".join(f'<si><t xml:space="preserve">{escape(s)}</t></si>' for s in shared) + "</sst>")
+    wb = (f'<?xml version="1.0" encoding="UTF-8"?><workbook {ns} '
+          'xmlns:r="http://schemas.openxmlformats.org/officeDocument/2006/relationships"><sheets>'
+          f'<sheet name="{escape(sheet_name)}" sheetId="1" r:id="rId1"/></sheets></workbook>')
+    rels = ('<?xml version="1.0" encoding="UTF-8"?>'
+            '<Relationships xmlns="http://schemas.openxmlformats.org/package/2006/relationships">'
+            '<Relationship Id="rId1" Type="http://schemas.openxmlformats.org/officeDocument/2006/relationships/worksheet" '
+            'Target="worksheets/sheet1.xml"/>'
+            '<Relationship Id="rId2" Type="http://schemas.openxmlformats.org/officeDocument/2006/relationships/sharedStrings" '
+            'Target="sharedStrings.xml"/></Relationships>')
+    ctypes_ = ('<?xml version="1.0" encoding="UTF-8"?><Types xmlns="http://schemas.openxmlformats.org/package/2006/content-types">'
+               '<Default Extension="rels" ContentType="application/vnd.openxmlformats-package.relationships+xml"/>'
+               '<Default Extension="xml" ContentType="application/xml"/></Types>')
+    root_rels = ('<?xml version="1.0" encoding="UTF-8"?>'
+                 '<Relationships xmlns="http://schemas.openxmlformats.org/package/2006/relationships">'
+                 '<Relationship Id="rId1" Type="http://schemas.openxmlformats.org/officeDocument/2006/relationships/officeDocument" '
+                 'Target="xl/workbook.xml"/></Relationships>')
+    with zipfile.ZipFile(path, "w", zipfile.ZIP_DEFLATED) as z:
+        z.writestr("[Content_Types].xml", ctypes_)
+        z.writestr("_rels/.rels", root_rels)
+        z.writestr("xl/workbook.xml", wb)
+        z.writestr("xl/_rels/workbook.xml.rels", rels)
+        z.writestr("xl/sharedStrings.xml", sst)
+        z.writestr("xl/worksheets/sheet1.xml", sheet)

@@ -53,13 +53,22 @@ def find_similar_products_bidirectional(query_description: str, vector_db, n_res
         return []
     if not res or not res.get("ids"):
         return []
-    ids, dists = res["ids"][0], res["distances"][0]
-    metas, embs = res["metadatas"][0], res["embeddings"][0]
     docs = (res.get("documents") or [[]])[0]
+    q_back = np.asarray(emb.embed_query(normalize_description(query_description)))
+    return bidirectional_filter_row(query_description, q_back, res["distances"][0], res["metadatas"][0],
+                                    res["embeddings"][0], docs, n_results_final, similarity_threshold_forward,
+                                    similarity_threshold_backward)
+
+
+def bidirectional_filter_row(query_description: str, q_back: np.ndarray, dists, metas, embs, docs,
+                             n_results_final: int, similarity_threshold_forward: float,
+                             similarity_threshold_backward: float) -> List[Dict[str, Any]]:
+    """The per-candidate stage of analysis/bidirectional_similarity.py:140-194 on ONE
+    query's result row; shared by the single-query call above and the batched
+    harness (analysis.test_bidirectional_similarity)."""
     q_norm_text = normalize_description(query_description)
-    q_back = np.asarray(emb.embed_query(q_norm_text))
     matches = []
-    for i in range(len(ids)):
+    for i in range(len(dists)):
         fwd = 1 - dists[i]
         if fwd < similarity_threshold_forward:
             continue
