@@ -247,7 +247,7 @@ def test_million_rows_properties(hip_lib, oracle_mod):
 # ----------------------------------------------------------------------------
 # batched MFMA path (bf16 store, B >= 16)
 # ----------------------------------------------------------------------------
-@pytest.mark.parametrize("b", [16, 100, 128, 300])
+@pytest.mark.parametrize("b", [16, 100, 128, 200, 256, 300, 512])   # 200/256/512 take the 256-wide tile, the rest the 128-wide
 def test_mfma_batch_parity(hip_lib, oracle_mod, corpus20k, b):
     """Q.D^T on MFMA + fused top-k' + fp32 rerank vs the exact oracle.  Every corpus
     tile's first pass overflows the LDS candidate queue (all scores beat -inf), so the
@@ -294,6 +294,47 @@ def test_mfma_multi_tile_per_block_and_selfjoin(hip_lib, oracle_mod):
         q = rows[1000 + j:1001 + j]
         m_idx, m_dist, m_sc = oracle_mod.exact_topk(masked, q, 5)
         check_topk(sj_idx[j:j + 1], sj_dist[j:j + 1], m_idx, m_dist, m_sc, rows, q, what=f"mfma selfjoin q{j}")
+    ix.close()
+
+
+@pytest.mark.parametrize("variant", [3, 4])
+def test_mfma_kernel_variants_agree(hip_lib, oracle_mod, corpus20k, variant):
+    """The three pass-kernel formulations (barrier ring, warp-specialised, wide tile) are
+    interchangeable: same ids and distances on the same batch."""
+    n, dim, spec, rows, _ = corpus20k
+    qspec = SynthSpec(seed=4242, kind=2, noise=0.5, base_kind=1, base_seed=1234, base_n=n, base_n_clusters=141, base_noise=0.3)
+    queries = oracle_mod.synth_rows(0, 256, dim, qspec)
+    ix = FlatIndex(dim, "bf16", True)
+    ix.add_synth(0, n, spec)
+    i5, d5 = ix.search(queries, 10, 40)
+    ix.set_option("mfma_variant", variant)
+    iv, dv = ix.search(queries, 10, 40)
+    assert np.array_equal(iv, i5) and np.array_equal(dv, d5)
+    ix.close()
+
+
+def test_mfma_wide_multi_tile_and_selfjoin(hip_lib, oracle_mod):
+    """The 256-wide tile with several corpus tiles per block, a ragged last corpus tile, a
+    ragged query tile (450 of 512) and the self-join exclusion."""
+    n, dim, b = 150001, 768, 450
+    spec = SynthSpec(seed=177, kind=1, n_clusters=387, noise=0.3)
+    qspec = SynthSpec(seed=178, kind=2, noise=0.5, base_kind=1, base_seed=177, base_n=n, base_n_clusters=387, base_noise=0.3)
+    rows = oracle_mod.normalize_rows(oracle_mod.synth_rows(0, n, dim, spec))
+    queries = oracle_mod.synth_rows(0, b, dim, qspec)
+    ix = FlatIndex(dim, "bf16", True)
+    ix.add_synth(0, n, spec)
+    idx, dist = ix.search(queries, 10, 40)
+    assert ix.get_stat("mfma_last_overflow") == 0
+    r_idx, r_dist, r_sc = oracle_mod.exact_topk(rows, queries, 10)
+    check_topk(idx, dist, r_idx, r_dist, r_sc, rows, _qn(oracle_mod, queries), what="mfma wide 150k")
+    sj_idx, sj_dist = ix.selfjoin(5, exclude_self=True, rerank_kprime=40, q_row0=149700, q_n=256)
+    assert not np.any(sj_idx == (149700 + np.arange(256))[:, None])
+    for j in (0, 100, 255):
+        masked = rows.copy()
+        masked[149700 + j] = 0
+        q = rows[149700 + j:149701 + j]
+        m_idx, m_dist, m_sc = oracle_mod.exact_topk(masked, q, 5)
+        check_topk(sj_idx[j:j + 1], sj_dist[j:j + 1], m_idx, m_dist, m_sc, rows, q, what=f"mfma wide selfjoin q{j}")
     ix.close()
 
 

@@ -16,6 +16,7 @@
 #include "select.h"
 #include "synth.h"
 #include "scan_mfma4.h"
+#include "scan_mfma5.h"
 
 using namespace vdbk;
 
@@ -51,7 +52,8 @@ struct vdb {
   DevBuf w_q, w_part_s, w_part_i, w_part2_s, w_part2_i, w_stage, w_out_i, w_out_d, w_idx, w_mfma;
   DevBuf w_cand_s, w_cand_i, w_cand_cnt, w_thr, w_dense, w_list_s, w_list_i;   // append-path state
   int mfma_append_cap = 16384;   // candidate buffer entries per query
-  int mfma_variant = 4;          // 3 = barrier ring (scan_mfma3.h), 4 = warp-specialised (scan_mfma4.h)
+  int mfma_variant = 5;          // 3 = barrier ring (scan_mfma3.h), 4 = warp-specialised (scan_mfma4.h),
+                                 // 5 = 256x256 tile (scan_mfma5.h) when that pads the batch no further, else 4
   int mfma_last_b = 0;           // batch size of the last MFMA search (locates its overflow flag)
   int mfma_force_fallback = 0;   // test hook: route through the exact list kernel
   std::string err;
@@ -269,13 +271,18 @@ int mfma_search(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
                 float* out_dist, hipStream_t st) {
   const int kk = kp ? kp : k;
   const int n_rows = (int)h->n;
-  const int n_qt = (b + kMfBN - 1) / kMfBN;
+  const int n_qt_fb = (b + kMfBN - 1) / kMfBN;          // query tiles of the 128-wide kernels (incl. the fallback)
+  // the 256-wide tile serves the batch when it pads it no further than the 128-wide one does
+  const bool wide = h->mfma_variant == 5 && ((b + kM5BN - 1) / kM5BN) * kM5BN == n_qt_fb * kMfBN;
+  const int variant = h->mfma_variant == 5 ? (wide ? 5 : 4) : h->mfma_variant;
+  const int n_qt = wide ? (b + kM5BN - 1) / kM5BN : n_qt_fb;
+  const int b_pad = n_qt_fb * kMfBN;                     // == n_qt * kM5BN when wide
   const long long n_tiles = ((long long)n_rows + kMfBM - 1) / kMfBM;
   const int cap = h->mfma_append_cap;
   const int self0 = self_row0 >= 0 ? (int)self_row0 : -1;
   const unsigned char* rows = (const unsigned char*)h->rows_bf16;
   int rc;
-  if ((rc = ensure(h, h->w_mfma, (size_t)n_qt * kMfBN * kMfDim * 2))) return rc;
+  if ((rc = ensure(h, h->w_mfma, (size_t)b_pad * kMfDim * 2))) return rc;
   if ((rc = ensure(h, h->w_cand_s, (size_t)b * cap * 4))) return rc;
   if ((rc = ensure(h, h->w_cand_i, (size_t)b * cap * 4))) return rc;
   if ((rc = ensure(h, h->w_cand_cnt, (size_t)(b + 16) * 4))) return rc;   // [b] counters + overflow flag at [b]
@@ -283,7 +290,7 @@ int mfma_search(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
   if ((rc = ensure(h, h->w_dense, (size_t)b * kMf3DenseLd * 4))) return rc;
   if ((rc = ensure(h, h->w_list_s, (size_t)b * kk * 4))) return rc;
   if ((rc = ensure(h, h->w_list_i, (size_t)b * kk * 4))) return rc;
-  const MfGrid fb = mf_grid(h->n_cu, n_qt, n_tiles, 64);   // fallback grid (<= 64 partial lists per query)
+  const MfGrid fb = mf_grid(h->n_cu, n_qt_fb, n_tiles, 64);   // fallback grid (<= 64 partial lists per query)
   const size_t part_elems = (size_t)b * fb.n_splits * kk;
   if ((rc = ensure(h, h->w_part_s, part_elems * 4))) return rc;
   if ((rc = ensure(h, h->w_part_i, part_elems * 4))) return rc;
@@ -294,6 +301,8 @@ int mfma_search(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
     HIP_TRY(h, hipFuncSetAttribute((const void*)scan_mfma_pass_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kMfNumStages * kMfStage));
     HIP_TRY(h, hipFuncSetAttribute((const void*)scan_mfma_ws_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_smem_bytes()));
     HIP_TRY(h, hipFuncSetAttribute((const void*)scan_mfma_ws_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_smem_bytes()));
+    HIP_TRY(h, hipFuncSetAttribute((const void*)scan_mfma_wide_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m5_smem_bytes()));
+    HIP_TRY(h, hipFuncSetAttribute((const void*)scan_mfma_wide_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m5_smem_bytes()));
     attr_set = true;
   }
   const unsigned char* qb16 = (const unsigned char*)h->w_mfma.p;
@@ -308,8 +317,8 @@ int mfma_search(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
   int* list_i = (int*)h->w_list_i.p;
   const size_t smem3 = (size_t)kMfNumStages * kMfStage;
 
-  hipLaunchKernelGGL(queries_to_bf16_kernel, dim3(std::min(1024, (n_qt * kMfBN * kMfDim + 255) / 256)), dim3(256), 0, st,
-                     qn, b, n_qt * kMfBN, (uint16_t*)h->w_mfma.p);
+  hipLaunchKernelGGL(queries_to_bf16_kernel, dim3(std::min(1024, (b_pad * kMfDim + 255) / 256)), dim3(256), 0, st,
+                     qn, b, b_pad, (uint16_t*)h->w_mfma.p);
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipMemsetAsync(ovf, 0, 4, st));
   h->last_bytes = 0.0;
@@ -319,7 +328,11 @@ int mfma_search(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
   {
     const int stride = (int)std::max<long long>(1, n_tiles / t_cur);
     const MfGrid g = mf_grid(h->n_cu, n_qt, t_cur, 1 << 30);
-    if (h->mfma_variant == 4)
+    if (variant == 5)
+      hipLaunchKernelGGL((scan_mfma_wide_kernel<0>), dim3(n_qt * g.n_splits), dim3(kM5Threads), m5_smem_bytes(), st, rows, n_rows, qb16, b,
+                         n_qt, g.n_splits, g.tiles_per_split, (int)t_cur, stride, self0, g.xcd_map, (const float*)nullptr, dense,
+                         (int*)nullptr, (float*)nullptr, (int*)nullptr, 0, 0);
+    else if (variant == 4)
       hipLaunchKernelGGL((scan_mfma_ws_kernel<0>), dim3(n_qt * g.n_splits), dim3(kWsThreads), ws_smem_bytes(), st, rows, n_rows, qb16, b,
                          n_qt, g.n_splits, g.tiles_per_split, (int)t_cur, stride, self0, g.xcd_map, (const float*)nullptr, dense,
                          (int*)nullptr, (float*)nullptr, (int*)nullptr, 0, ovf, 0);
@@ -344,7 +357,11 @@ int mfma_search(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
     const int stride = last ? 1 : (int)std::max<long long>(1, n_tiles / t_next);
     HIP_TRY(h, hipMemsetAsync(cand_cnt, 0, (size_t)b * 4, st));
     const MfGrid g = mf_grid(h->n_cu, n_qt, t_next, 1 << 30);
-    if (h->mfma_variant == 4)
+    if (variant == 5)
+      hipLaunchKernelGGL((scan_mfma_wide_kernel<1>), dim3(n_qt * g.n_splits), dim3(kM5Threads), m5_smem_bytes(), st, rows, n_rows, qb16, b,
+                         n_qt, g.n_splits, g.tiles_per_split, (int)t_next, stride, self0, g.xcd_map, (const float*)thr, dense,
+                         cand_cnt, cand_s, cand_i, cap, h->mfma_ablate);
+    else if (variant == 4)
       hipLaunchKernelGGL((scan_mfma_ws_kernel<1>), dim3(n_qt * g.n_splits), dim3(kWsThreads), ws_smem_bytes(), st, rows, n_rows, qb16, b,
                          n_qt, g.n_splits, g.tiles_per_split, (int)t_next, stride, self0, g.xcd_map, (const float*)thr, dense,
                          cand_cnt, cand_s, cand_i, cap, ovf, h->mfma_ablate);
@@ -361,8 +378,8 @@ int mfma_search(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
   }
   if (h->mfma_force_fallback) HIP_TRY(h, hipMemsetAsync(ovf, 1, 1, st));
   // exact list kernel: returns at once unless the overflow flag is set
-  hipLaunchKernelGGL(scan_mfma_topk_kernel, dim3(n_qt * fb.n_splits), dim3(kMfThreads), mf_smem_bytes(), st, rows, n_rows, qb16, b,
-                     n_qt, fb.n_splits, fb.tiles_per_split, kk, self0, fb.xcd_map, h->mfma_ablate, (const int*)ovf,
+  hipLaunchKernelGGL(scan_mfma_topk_kernel, dim3(n_qt_fb * fb.n_splits), dim3(kMfThreads), mf_smem_bytes(), st, rows, n_rows, qb16, b,
+                     n_qt_fb, fb.n_splits, fb.tiles_per_split, kk, self0, fb.xcd_map, h->mfma_ablate, (const int*)ovf,
                      (float*)h->w_part_s.p, (int*)h->w_part_i.p);
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipEventRecord(h->ev[1], st));
@@ -824,7 +841,7 @@ int vdb_set_option(vdb_t* h, const char* name, int64_t value) {
   if (!strcmp(name, "scan_nt_loads")) { h->scan_nt_loads = value != 0; return VDB_OK; }
   if (!strcmp(name, "mfma_ablate")) { h->mfma_ablate = (int)value; return VDB_OK; }
   if (!strcmp(name, "mfma_variant")) {
-    if (value != 3 && value != 4) return fail(h, VDB_ERR_ARG, "mfma_variant must be 3 or 4");
+    if (value < 3 || value > 5) return fail(h, VDB_ERR_ARG, "mfma_variant must be 3, 4 or 5");
     h->mfma_variant = (int)value; return VDB_OK;
   }
   if (!strcmp(name, "mfma_force_fallback")) { h->mfma_force_fallback = value != 0; return VDB_OK; }
