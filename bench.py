@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--nt", type=int, default=-1)
     ap.add_argument("--mfma-variant", type=int, default=0)
+    ap.add_argument("--stage-dist", type=int, default=-1)
     ap.add_argument("--clusters", type=int, default=0, help="synthetic clusters (default sqrt(rows))")
     ap.add_argument("--ablate", type=int, default=0, help="diagnostic: MFMA kernel ablation bits (results invalid)")
     args = ap.parse_args()
@@ -114,6 +115,8 @@ def main():
         sh.local.set_option("scan_blocks_per_cu", args.blocks_per_cu)
     if args.mfma_variant:
         sh.local.set_option("mfma_variant", args.mfma_variant)
+    if args.stage_dist >= 0:
+        sh.local.set_option("mfma_stage_dist", args.stage_dist)
     if args.ablate:
         sh.local.set_option("mfma_ablate", args.ablate)
     if args.nt >= 0:

@@ -1,0 +1,99 @@
+// lds_dma_probe.hip — what the L2 -> LDS path (global_load_lds_dwordx4) delivers per CU as a
+// function of (a) bytes kept in flight and (b) the row-segment width of a piece.  Design input
+// for the staging of scan_mfma5.h; not part of the library.
+//
+//   hipcc --offload-arch=gfx950 -O3 -o lds_dma_probe lds_dma_probe.hip && ./lds_dma_probe
+//
+// One 512-thread block per CU.  Every wave loops over "stages"; a stage is SLOTS 1 KiB pieces
+// per wave.  KEEP stages stay in flight across each step's barrier (counted s_waitcnt vmcnt), so bytes in flight per CU
+// = 8 waves x RING x SLOTS KiB.  SEG = 128: a piece covers 8 rows x 128 B (one full line per row
+// and K-step).  SEG = 64: a piece covers 16 rows x 64 B and the other half of each line is
+// fetched by the NEXT stage (what a K=32 stage would do).  Source: a [rows][1536 B] matrix; all
+// blocks of an XCD walk the same rows (L2-shared, as the kernel's query/corpus tiles are).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+__device__ __forceinline__ void glds16(const unsigned char* g, unsigned char* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+template <int SEG, int KEEP, int SLOTS>
+__global__ __launch_bounds__(512) void probe(const unsigned char* __restrict__ src, long long n_rows, int n_stages, int rows_per_block_stage) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  constexpr int RING = KEEP + 1;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int xcd = blockIdx.x & 7;
+  // rows walked by this XCD's blocks: a window that advances by rows_per_block_stage per stage
+  const long long xcd_rows = n_rows / 8;
+  const unsigned char* base = src + (size_t)xcd * xcd_rows * 1536;
+  constexpr int ROWS_PER_PIECE = 1024 / SEG;
+  const unsigned lane_off = (unsigned)((lane / (SEG / 16)) * 1536 + (lane % (SEG / 16)) * 16);
+  auto issue = [&](int stage) {
+    // SEG=128: K-step = stage % 12, row window advances every 12 stages.  SEG=64: 24 half steps.
+    constexpr int KSTEPS = 1536 / SEG;
+    const int ks = stage % KSTEPS;
+    const long long win = ((long long)(stage / KSTEPS) * rows_per_block_stage) % (xcd_rows - rows_per_block_stage);
+    const unsigned char* p = base + (size_t)win * 1536 + (size_t)ks * SEG + (size_t)w * SLOTS * ROWS_PER_PIECE * 1536;
+    unsigned char* st = smem + ((stage % RING) * 8 + w) * SLOTS * 1024;
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i) glds16(p + (size_t)i * ROWS_PER_PIECE * 1536 + lane_off, st + i * 1024);
+  };
+#pragma unroll
+  for (int s = 0; s < KEEP; ++s) issue(s);
+  for (int s = 0; s < n_stages; ++s) {
+    issue(s + KEEP);
+    // stage s has landed once only the KEEP younger stages are outstanding (KEEP = 0: the
+    // burst-then-drain pattern of a two-buffer kernel that refills right behind its barrier)
+    if constexpr (KEEP * SLOTS == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (KEEP * SLOTS == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (KEEP * SLOTS == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if constexpr (KEEP * SLOTS == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if constexpr (KEEP * SLOTS == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int SEG, int KEEP, int SLOTS>
+void run(const unsigned char* d, long long n_rows, const char* what) {
+  const int n_stages = 6000;
+  const int rows_per_block_stage = 8 * SLOTS * (1024 / SEG);   // rows one block covers per stage
+  const size_t smem = (size_t)(KEEP + 1) * 8 * SLOTS * 1024;
+  CHECK(hipFuncSetAttribute((const void*)probe<SEG, KEEP, SLOTS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  for (int rep = 0; rep < 2; ++rep) {
+    CHECK(hipEventRecord(e0));
+    hipLaunchKernelGGL((probe<SEG, KEEP, SLOTS>), dim3(256), dim3(512), smem, 0, d, n_rows, n_stages, rows_per_block_stage);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+  }
+  float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+  const double bytes = 256.0 * n_stages * 8 * SLOTS * 1024;
+  printf("%-34s seg %3d B  kept in flight/CU %3d KiB  stage %2d KiB : %6.2f ms  %6.2f TB/s  %5.1f GB/s per CU\n", what, SEG,
+         KEEP * 8 * SLOTS, 8 * SLOTS, ms, bytes / ms / 1e9, bytes / ms / 1e6 / 256);
+}
+
+int main() {
+  const long long n_rows = 1 << 20;   // 1.5 GiB matrix
+  unsigned char* d;
+  CHECK(hipMalloc(&d, (size_t)n_rows * 1536));
+  CHECK(hipMemset(d, 1, (size_t)n_rows * 1536));
+  run<128, 0, 8>(d, n_rows, "64 KiB burst, drained each step");
+  run<128, 1, 8>(d, n_rows, "64 KiB stages, 1 kept");
+  run<128, 1, 4>(d, n_rows, "32 KiB stages, 1 kept");
+  run<128, 2, 4>(d, n_rows, "32 KiB stages, 2 kept");
+  run<128, 3, 4>(d, n_rows, "32 KiB stages, 3 kept");
+  run<64, 0, 4>(d, n_rows, "32 KiB half-line burst, drained");
+  run<64, 1, 4>(d, n_rows, "32 KiB half-line stages, 1 kept");
+  run<64, 2, 4>(d, n_rows, "32 KiB half-line stages, 2 kept");
+  run<64, 3, 4>(d, n_rows, "32 KiB half-line stages, 3 kept");
+  CHECK(hipFree(d));
+  return 0;
+}

@@ -27,7 +27,7 @@
 
 namespace vdbk {
 
-constexpr int kMf3DenseTiles = 4;                      // dense sample: 4 tiles = 1024 rows
+constexpr int kMf3DenseTiles = 16;                     // dense sample: 16 tiles = 4096 rows
 constexpr int kMf3DenseLd = kMf3DenseTiles * kMfBM;
 
 // MODE 0: dense sample scores -> dense[q][t*256 + r].  MODE 1: append hits to cand_*[q][cap].

@@ -11,17 +11,24 @@
 //
 // Structure (512 threads = 8 waves, 2(M) x 4(N), two waves per SIMD, <= 256 registers):
 //   * two 64 KiB LDS stages [A 256 rows | B 256 rows] x 128 B, chunk-swizzled as before;
-//     every wave stages 8 KiB per K-step with 8 global_load_lds_dwordx4;
+//     every wave stages 8 KiB per K-step with 8 global_load_lds_dwordx4; the 12 K-steps of a
+//     tile are unrolled, so stage parity, K offsets and the first step's zero accumulator
+//     (MFMA with C = 0: no 128-register clear per tile) are compile-time;
 //   * ONE block barrier per K-step, placed before the last of its four k16 sub-steps:
 //     it certifies both that the next stage has landed (each wave waits for its own
 //     loads first) and that everybody's reads of the current stage have returned, so the
 //     current buffer is refilled for step+2 right behind it — a full step of flight time;
 //   * fragments are double-buffered in registers: the reads of sub-step j+1 (across the
 //     stage boundary too) are issued before the MFMAs of sub-step j, so no MFMA waits on LDS;
-//   * epilogue: per 32x32 block a max-reduction of the lane's 16 scores and one ballot decide
-//     whether any score reaches the query's threshold; only then are the 16 examined.
+//   * epilogue: VALU time is what it costs (two waves share a SIMD and reach it together), so
+//     it is a max tree: per 32x32 block the lane's 16 scores reduce to four group maxima and
+//     one block maximum; one ballot per block, then one per hot group of four, and only those
+//     four scores are examined.  Hits go to a per-wave LDS queue (three ds_write_b32) and are
+//     moved to the candidate buffers 64 at a time, so the returning global atomic that
+//     reserves a slot is paid per drain, not per hit.
 // Thresholds, append buffers, exactness argument and fallback are those of scan_mfma3.h.
 #pragma once
+#include <type_traits>
 #include "scan_mfma3.h"
 
 namespace vdbk {
@@ -33,15 +40,15 @@ constexpr int kM5Stage = kM5StageA + kM5StageB;     // 64 KiB
 constexpr int kM5NumStages = 2;
 constexpr int kM5Threads = 512;
 
-__host__ __device__ constexpr size_t m5_smem_bytes() { return (size_t)kM5NumStages * kM5Stage; }
+__host__ __device__ constexpr size_t m5_smem_bytes() { return (size_t)kM5NumStages * kM5Stage + 8 * 256 * 12; }   // + per-wave hit queues
 
-template <int MODE>
+template <int MODE, int LP>
 __global__ __launch_bounds__(kM5Threads) void scan_mfma_wide_kernel(
     const unsigned char* __restrict__ rows, int n_rows, const unsigned char* __restrict__ qb16, int b, int n_qtiles,
     int n_splits, int tiles_per_split, int n_pass_tiles, int tile_stride, int self0, int xcd_map,
     const float* __restrict__ thr_in, float* __restrict__ dense, int* __restrict__ cand_cnt,
     float* __restrict__ cand_s, int* __restrict__ cand_i, int cap, int ablate) {
-  extern __shared__ __align__(16) unsigned char smem[];   // the only LDS object: 2 stages
+  extern __shared__ __align__(16) unsigned char smem[];   // the only LDS object: 2 stages + 8 hit queues
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -61,8 +68,7 @@ __global__ __launch_bounds__(kM5Threads) void scan_mfma_wide_kernel(
   const int tile0 = sp * tiles_per_split;
   const int tile1 = min(tile0 + tiles_per_split, n_pass_tiles);
   const int my_tiles = tile1 > tile0 ? tile1 - tile0 : 0;
-  const int total_steps = my_tiles * kMfSteps;
-  if (total_steps == 0) return;
+  if (my_tiles == 0) return;
 
   float thr[2] = {-INFINITY, -INFINITY};
   if (MODE == 1 && thr_in) {
@@ -82,19 +88,21 @@ __global__ __launch_bounds__(kM5Threads) void scan_mfma_wide_kernel(
   }
   const int wbase16 = w * 1024;
   const unsigned char* qblk = qb16 + (size_t)qbase * kMfRowBytes;
-
-  int is_tile = 0, is_ks = 0;   // staging cursor (scalar)
-  auto issue = [&](int buf) {
-    const unsigned char* abase = rows + (size_t)(tile0 + is_tile) * tile_stride * (kMfBM * kMfRowBytes) + is_ks * (kMfBK * 2);
-    const unsigned char* bbase = qblk + is_ks * (kMfBK * 2);
-    unsigned char* st = smem + buf * kM5Stage + wbase16;
-    if (!(ablate & 1)) {   // ablate bit 0: diagnostic timing runs without the loads (results invalid)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) mf_glds16(abase + g_off[t], st + t * (kM5Threads * 16));
-#pragma unroll
-      for (int t = 0; t < 4; ++t) mf_glds16(bbase + g_off[t], st + kM5StageA + t * (kM5Threads * 16));
-    }
-    if (++is_ks == kMfSteps) { is_ks = 0; ++is_tile; }
+  const size_t tile_bytes = (size_t)tile_stride * (kMfBM * kMfRowBytes);
+  const unsigned char* ta = rows + (size_t)tile0 * tile_bytes;   // corpus tile being multiplied
+  const unsigned char* tn = my_tiles > 1 ? ta + tile_bytes : ta; // the one after it (the last tile names itself:
+                                                                 // its two trailing stage loads land in buffers nobody reads)
+  // piece i (0..3 corpus, 4..7 queries; 1 KiB per wave) of stage s_abs = K-step index counted from
+  // the current tile's first (12, 13 = the next tile's first two); 12 is even, so parity = buffer
+  // `partner`: the same piece of the wave that shares this wave's SIMD (w ^ 4: 32 rows further on or back)
+  const long long pd_g = wm == 0 ? 32 * kMfRowBytes : -32 * kMfRowBytes;
+  const int pd_l = wm == 0 ? 4096 : -4096;
+  auto piece = [&](int i, int s_abs, bool partner) {
+    const bool wrap = s_abs >= kMfSteps;
+    const long long koff = (wrap ? s_abs - kMfSteps : s_abs) * (kMfBK * 2) + (partner ? pd_g : 0);
+    unsigned char* st = smem + (s_abs & 1) * kM5Stage + wbase16 + (partner ? pd_l : 0);
+    if (i < 4) mf_glds16((wrap ? tn : ta) + koff + g_off[i], st + i * (kM5Threads * 16));
+    else mf_glds16(qblk + koff + g_off[i - 4], st + kM5StageA + (i - 4) * (kM5Threads * 16));
   };
 
   // fragment reads: k16 sub-step s uses chunk 2s+hsel of rows (lane&31) + 32*block
@@ -106,7 +114,8 @@ __global__ __launch_bounds__(kM5Threads) void scan_mfma_wide_kernel(
   for (int s = 0; s < 4; ++s) ck[s] = ((2 * s + hsel) ^ swz) << 4;
 
   bf16x8_t fA[2][4], fB[2][2];
-  auto read_frags = [&](int fbuf, const unsigned char* sb, int s) {
+  auto read_frags = [&](int fbuf, int stage_buf, int s) {
+    const unsigned char* sb = smem + stage_buf * kM5Stage;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) fA[fbuf][mt] = *reinterpret_cast<const bf16x8_t*>(sb + a_row_off + ck[s] + mt * 4096);
 #pragma unroll
@@ -114,65 +123,118 @@ __global__ __launch_bounds__(kM5Threads) void scan_mfma_wide_kernel(
   };
 
   f32x16_t acc[4][2];
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
-
-  auto mfma8 = [&](int fbuf) {
+  auto mfma8 = [&](int fbuf, bool first) {
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fA[fbuf][mt], fB[fbuf][nt], acc[mt][nt], 0, 0, 0);
-  };
-  // one k16 sub-step: the next sub-step's 6 fragment reads go out between this one's 8 MFMAs
-  auto pin_schedule = [&]() {
+      for (int nt = 0; nt < 2; ++nt) {
+        f32x16_t c = acc[mt][nt];
+        if (first) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+          for (int r = 0; r < 16; ++r) c[r] = 0.f;
+        }
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fA[fbuf][mt], fB[fbuf][nt], c, 0, 0, 0);
+      }
+  };
+  // one k16 sub-step = 8 MFMAs; between them go the next sub-step's 6 fragment reads and NV staging loads
+  auto pin_schedule = [&](auto nv_tag) {
+    constexpr int NV = decltype(nv_tag)::value;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       // 1 MFMA
+      if (i < 6) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);            // 1 DS read
+      const int nv = ((i + 1) * NV) / 8 - (i * NV) / 8;                        // VMEM (LDS-DMA) after this MFMA
+      if (nv == 1) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      if (nv == 2) __builtin_amdgcn_sched_group_barrier(0x010, 2, 0);
     }
-    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+  };
+  using NV0 = std::integral_constant<int, 0>;
+
+  // per-wave hit queue in LDS, behind the two stages
+  constexpr int kQCap = 256;
+  float* q_s = reinterpret_cast<float*>(smem + kM5NumStages * kM5Stage + w * (kQCap * 12));
+  int* q_r = reinterpret_cast<int*>(q_s + kQCap);
+  int* q_q = q_r + kQCap;
+  int qn = 0;   // wave-uniform
+  auto drain = [&]() {
+    for (int base = 0; base < qn; base += 64) {
+      const int i = base + lane;
+      if (i < qn) {
+        const float s = q_s[i];
+        const int r = q_r[i], q = q_q[i];
+        const int pos = atomicAdd(&cand_cnt[q], 1);
+        if (pos < cap) { cand_s[(size_t)q * cap + pos] = s; cand_i[(size_t)q * cap + pos] = r; }
+      }
+    }
+    qn = 0;
   };
 
-  // prologue: stage 0 lands, stage 1 goes out, sub-step 0 fragments of stage 0 are read
-  issue(0);
+  // prologue: stage 0 lands, stage 1 starts, sub-step 0 fragments of stage 0 are read
+#pragma unroll
+  for (int i = 0; i < 8; ++i) piece(i, 0, false);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  if (total_steps > 1) issue(1);
-  read_frags(0, smem, 0);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) piece(i, 1, false);
+  read_frags(0, 0, 0);
 
-  int buf = 0, ks = 0, tile = 0;
-  for (int step = 0; step < total_steps; ++step) {
-    const unsigned char* sb = smem + buf * kM5Stage;
-    const unsigned char* sbn = smem + (buf ^ 1) * kM5Stage;
-    read_frags(1, sb, 1);
-    mfma8(0);
-    pin_schedule();
-    read_frags(0, sb, 2);
-    mfma8(1);
-    pin_schedule();
-    read_frags(1, sb, 3);
-    mfma8(0);
-    pin_schedule();
+  // one K-step; the stage parity `buf` and `first` (first step of a tile: C = 0) are compile-time,
+  // the K-step index ks is a scalar
+  auto step = [&](auto buf_tag, auto first_tag, int ks) {
+    constexpr int buf = decltype(buf_tag)::value;
+    constexpr bool first = decltype(first_tag)::value != 0;
+    read_frags(1, buf, 1);
+    mfma8(0, first);
+    pin_schedule(NV0{});
+    read_frags(0, buf, 2);
+    mfma8(1, false);
+    pin_schedule(NV0{});
+    read_frags(1, buf, 3);
+    mfma8(0, false);
+    pin_schedule(NV0{});
     // every read of this stage has returned and my share of the next stage has landed -> barrier
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (step + 2 < total_steps) issue(buf);              // refill the buffer just released, for step+2
-    // first fragments of the next stage (after the last step this reads a stale buffer and the values
-    // are dropped: keeping it unconditional keeps the wait before the MFMAs a counted one)
-    read_frags(0, sbn, 0);
-    mfma8(1);
-    pin_schedule();
-    buf ^= 1;
-    if (++ks < kMfSteps) continue;
-    ks = 0;
-    if (ablate & 4) { ++tile; continue; }   // ablate bit 2: no epilogue
+    // Refill the buffer just released, for step+2, and read the first fragments of the next stage.
+    // An LDS-DMA instruction holds its wave's issue slot ~100 cycles while the L2->LDS path is busy,
+    // and a wave stuck there issues no MFMAs.  With LP > 8 the two waves of a SIMD (w, w^4) take
+    // turns: this step's loader issues LP of the pair's 16 pieces, its partner the other 16-LP, so
+    // one of them keeps the matrix pipe fed while the other feeds the memory pipe.
+    if (LP == 8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) piece(j, ks + 2, false);
+      read_frags(0, buf ^ 1, 0);
+      mfma8(1, false);
+      pin_schedule(std::integral_constant<int, 8>{});
+    } else {
+      // (the branch holds only the loads: MFMAs inside it would make hipcc copy the accumulators at the join)
+      if (wm == buf) {
+#pragma unroll
+        for (int j = 0; j < LP; ++j) piece(j & 7, ks + 2, j >= 8);
+      } else {
+#pragma unroll
+        for (int j = LP - 8; j < 8; ++j) piece(j, ks + 2, false);
+      }
+      read_frags(0, buf ^ 1, 0);
+      mfma8(1, false);
+      pin_schedule(NV0{});
+    }
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+
+  for (int tile = 0; tile < my_tiles; ++tile) {
+    step(I0{}, I1{}, 0);
+    step(I1{}, I0{}, 1);
+    for (int ks = 2; ks < kMfSteps; ks += 2) {
+      step(I0{}, I0{}, ks);
+      step(I1{}, I0{}, ks + 1);
+    }
+    ta = tn;
+    if (tile + 2 < my_tiles) tn += tile_bytes;
+    if (ablate & 4) continue;   // ablate bit 2: no epilogue (diagnostic, results invalid)
 
     // ---------------- epilogue of pass-local tile (tile0 + tile) ----------------
     const long long tile_row0 = (long long)(tile0 + tile) * tile_stride * kMfBM;
@@ -192,31 +254,38 @@ __global__ __launch_bounds__(kM5Threads) void scan_mfma_wide_kernel(
             if (qg < b) dense[(size_t)qg * kMf3DenseLd + (tile0 + tile) * kMfBM + rloc] = ok ? acc[mt][nt][reg] : -INFINITY;
           }
         } else {
-          float m = acc[mt][nt][0];
+          float m4[4];
 #pragma unroll
-          for (int reg = 1; reg < 16; ++reg) m = fmaxf(m, acc[mt][nt][reg]);
+          for (int g = 0; g < 4; ++g)
+            m4[g] = fmaxf(fmaxf(acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1]), fmaxf(acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]));
+          const float m = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
           if (__ballot(m >= thr[nt]) != 0ull) {
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-              const float v = acc[mt][nt][reg];
-              bool pass = v >= thr[nt];
-              if (pass) {
-                const int row = (int)tile_row0 + rbase + (reg & 3) + 8 * (reg >> 2);
-                if (needs_mask) pass = (row < n_rows) && (qg < b) && !(self0 >= 0 && row == self0 + qg);
-                if (pass) {
-                  const int pos = atomicAdd(&cand_cnt[qg], 1);
-                  if (pos < cap) { cand_s[(size_t)qg * cap + pos] = v; cand_i[(size_t)qg * cap + pos] = row; }
+            for (int g = 0; g < 4; ++g) {
+              if (__ballot(m4[g] >= thr[nt]) == 0ull) continue;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float v = acc[mt][nt][4 * g + e];
+                const int row = (int)tile_row0 + rbase + e + 8 * g;   // register 4g+e holds tile row rbase + e + 8g
+                bool pass = v >= thr[nt];
+                if (needs_mask) pass = pass && (row < n_rows) && (qg < b) && !(self0 >= 0 && row == self0 + qg);
+                const unsigned long long pb = __ballot(pass);
+                if (pb != 0ull) {
+                  if (qn > kQCap - 64) drain();
+                  const int slot = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(pb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)pb, 0u));
+                  if (pass) { q_s[slot] = v; q_r[slot] = row; q_q[slot] = qg; }
+                  qn += __popcll(pb);
                 }
               }
             }
           }
         }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
       }
     }
-    ++tile;
+    if (MODE == 1 && qn >= kQCap / 2) drain();
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing (unused) staging loads
+  if (MODE == 1) drain();
 }
 
 }  // namespace vdbk

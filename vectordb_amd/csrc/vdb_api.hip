@@ -52,6 +52,7 @@ struct vdb {
   DevBuf w_q, w_part_s, w_part_i, w_part2_s, w_part2_i, w_stage, w_out_i, w_out_d, w_idx, w_mfma;
   DevBuf w_cand_s, w_cand_i, w_cand_cnt, w_thr, w_dense, w_list_s, w_list_i;   // append-path state
   int mfma_append_cap = 16384;   // candidate buffer entries per query
+  int mfma_stage_dist = 8;       // wide kernel: staging loads per step issued by the loader wave of a SIMD pair (8 = each its own)
   int mfma_variant = 5;          // 3 = barrier ring (scan_mfma3.h), 4 = warp-specialised (scan_mfma4.h),
                                  // 5 = 256x256 tile (scan_mfma5.h) when that pads the batch no further, else 4
   int mfma_last_b = 0;           // batch size of the last MFMA search (locates its overflow flag)
@@ -301,8 +302,10 @@ int mfma_search(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
     HIP_TRY(h, hipFuncSetAttribute((const void*)scan_mfma_pass_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kMfNumStages * kMfStage));
     HIP_TRY(h, hipFuncSetAttribute((const void*)scan_mfma_ws_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_smem_bytes()));
     HIP_TRY(h, hipFuncSetAttribute((const void*)scan_mfma_ws_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_smem_bytes()));
-    HIP_TRY(h, hipFuncSetAttribute((const void*)scan_mfma_wide_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m5_smem_bytes()));
-    HIP_TRY(h, hipFuncSetAttribute((const void*)scan_mfma_wide_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m5_smem_bytes()));
+    HIP_TRY(h, hipFuncSetAttribute((const void*)scan_mfma_wide_kernel<0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m5_smem_bytes()));
+    HIP_TRY(h, hipFuncSetAttribute((const void*)scan_mfma_wide_kernel<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m5_smem_bytes()));
+    HIP_TRY(h, hipFuncSetAttribute((const void*)scan_mfma_wide_kernel<1, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m5_smem_bytes()));
+    HIP_TRY(h, hipFuncSetAttribute((const void*)scan_mfma_wide_kernel<1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m5_smem_bytes()));
     attr_set = true;
   }
   const unsigned char* qb16 = (const unsigned char*)h->w_mfma.p;
@@ -329,7 +332,7 @@ int mfma_search(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
     const int stride = (int)std::max<long long>(1, n_tiles / t_cur);
     const MfGrid g = mf_grid(h->n_cu, n_qt, t_cur, 1 << 30);
     if (variant == 5)
-      hipLaunchKernelGGL((scan_mfma_wide_kernel<0>), dim3(n_qt * g.n_splits), dim3(kM5Threads), m5_smem_bytes(), st, rows, n_rows, qb16, b,
+      hipLaunchKernelGGL((scan_mfma_wide_kernel<0, 8>), dim3(n_qt * g.n_splits), dim3(kM5Threads), m5_smem_bytes(), st, rows, n_rows, qb16, b,
                          n_qt, g.n_splits, g.tiles_per_split, (int)t_cur, stride, self0, g.xcd_map, (const float*)nullptr, dense,
                          (int*)nullptr, (float*)nullptr, (int*)nullptr, 0, 0);
     else if (variant == 4)
@@ -357,10 +360,12 @@ int mfma_search(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
     const int stride = last ? 1 : (int)std::max<long long>(1, n_tiles / t_next);
     HIP_TRY(h, hipMemsetAsync(cand_cnt, 0, (size_t)b * 4, st));
     const MfGrid g = mf_grid(h->n_cu, n_qt, t_next, 1 << 30);
-    if (variant == 5)
-      hipLaunchKernelGGL((scan_mfma_wide_kernel<1>), dim3(n_qt * g.n_splits), dim3(kM5Threads), m5_smem_bytes(), st, rows, n_rows, qb16, b,
+    if (variant == 5) {
+      auto kern = h->mfma_stage_dist == 16 ? scan_mfma_wide_kernel<1, 16> : h->mfma_stage_dist == 12 ? scan_mfma_wide_kernel<1, 12> : scan_mfma_wide_kernel<1, 8>;
+      hipLaunchKernelGGL(kern, dim3(n_qt * g.n_splits), dim3(kM5Threads), m5_smem_bytes(), st, rows, n_rows, qb16, b,
                          n_qt, g.n_splits, g.tiles_per_split, (int)t_next, stride, self0, g.xcd_map, (const float*)thr, dense,
                          cand_cnt, cand_s, cand_i, cap, h->mfma_ablate);
+    }
     else if (variant == 4)
       hipLaunchKernelGGL((scan_mfma_ws_kernel<1>), dim3(n_qt * g.n_splits), dim3(kWsThreads), ws_smem_bytes(), st, rows, n_rows, qb16, b,
                          n_qt, g.n_splits, g.tiles_per_split, (int)t_next, stride, self0, g.xcd_map, (const float*)thr, dense,
@@ -840,6 +845,10 @@ int vdb_set_option(vdb_t* h, const char* name, int64_t value) {
   }
   if (!strcmp(name, "scan_nt_loads")) { h->scan_nt_loads = value != 0; return VDB_OK; }
   if (!strcmp(name, "mfma_ablate")) { h->mfma_ablate = (int)value; return VDB_OK; }
+  if (!strcmp(name, "mfma_stage_dist")) {
+    if (value != 8 && value != 12 && value != 16) return fail(h, VDB_ERR_ARG, "mfma_stage_dist must be 8, 12 or 16");
+    h->mfma_stage_dist = (int)value; return VDB_OK;
+  }
   if (!strcmp(name, "mfma_variant")) {
     if (value < 3 || value > 5) return fail(h, VDB_ERR_ARG, "mfma_variant must be 3, 4 or 5");
     h->mfma_variant = (int)value; return VDB_OK;
