@@ -83,7 +83,6 @@ def main():
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--nt", type=int, default=-1)
     ap.add_argument("--mfma-variant", type=int, default=0)
-    ap.add_argument("--stage-dist", type=int, default=-1)
     ap.add_argument("--clusters", type=int, default=0, help="synthetic clusters (default sqrt(rows))")
     ap.add_argument("--ablate", type=int, default=0, help="diagnostic: MFMA kernel ablation bits (results invalid)")
     args = ap.parse_args()
@@ -115,8 +114,6 @@ def main():
         sh.local.set_option("scan_blocks_per_cu", args.blocks_per_cu)
     if args.mfma_variant:
         sh.local.set_option("mfma_variant", args.mfma_variant)
-    if args.stage_dist >= 0:
-        sh.local.set_option("mfma_stage_dist", args.stage_dist)
     if args.ablate:
         sh.local.set_option("mfma_ablate", args.ablate)
     if args.nt >= 0:
@@ -182,7 +179,8 @@ def main():
                 roof["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, separate pass)"
         except (OSError, KeyError, ValueError):
             pass
-        roof["kernel"] = "scan_mfma_topk_kernel" if mfma else "scan_topk_kernel"
+        wide = mfma and ((b + 255) // 256) * 256 == ((b + 127) // 128) * 128
+        roof["kernel"] = ("scan_mfma_wide_kernel<1> + sample passes" if wide else "scan_mfma_ws_kernel<1> + sample passes") if mfma else "scan_topk_kernel"
         roof["kernel_avg_ms"] = scan_ms
         roof["merge_rerank_avg_ms"] = tstats["merge_ms_sum"] / max(tstats["n"], 1)
         out = {
@@ -197,7 +195,8 @@ def main():
             "roofline": roof,
             "checks": {"planted_neighbour_first_and_ascending": planted_ok,
                        "mfma_overflow_fallback": sh.local.get_stat("mfma_last_overflow"),
-                       "mfma_hits_per_query": sh.local.get_stat("mfma_last_hits") / b},
+                       "mfma_hits_per_query": sh.local.get_stat("mfma_last_hits") / b,
+                       **({"prof": [sh.local.get_stat("mfma_prof_" + c) for c in "abcd"]} if args.ablate & 8 else {})},
             "build_s": t_build,
         }
         if world == 1 and not args.no_cpu_baseline:

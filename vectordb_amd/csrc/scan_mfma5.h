@@ -3,29 +3,40 @@
 //
 // Why: the 256x128 kernels (scan_mfma3.h / scan_mfma4.h) stage (1/128 + 1/256) bytes per
 // multiply-add column pair through LDS — 184 GB for 10M x 768 against 1024 queries — and the
-// L2 -> LDS path delivers ~66 GB/s per CU (~17 TB/s chip-wide, measured here and listed in
-// MI355X_MICROARCH.md "Indexed rows: gather into LDS"): 10.5 ms of pure operand delivery,
-// as long as the MFMA work itself.  A 256x256 tile stages 123 GB (7 ms), halves the LDS
-// fragment reads per MFMA (a wave owns 128 x 64: 6 ds_read_b128 feed 8 MFMAs instead of
-// 4 feeding 4), and leaves the matrix pipe as the limiter.
+// L2 -> LDS path delivers at most ~56 GB/s per CU (14.3 TB/s chip-wide; benchmarks/
+// lds_dma_probe.hip): 12.9 ms of operand delivery, longer than the MFMA work itself.  A
+// 256x256 tile stages 123 GB (8.6 ms) and halves the LDS fragment reads per MFMA (a wave owns
+// 128 x 64: 6 ds_read_b128 feed 8 MFMAs instead of 4 feeding 4).
+//
+// The same probe sets the shape of the staging ring.  That rate needs loads in flight ACROSS the
+// block barrier: a two-buffer kernel that refills right behind its barrier and drains before the
+// next one (64 KiB burst, then nothing) gets 39.8 GB/s per CU; with 32 KiB still in flight at
+// every barrier it is 56.  Half-line (64 B per row) pieces, i.e. K = 32 stages, get 37: the
+// stage stays K = 64.  Three whole 64 KiB stages do not fit in 160 KiB of LDS, so the operands
+// ring separately: THREE 32 KiB corpus slots and TWO 32 KiB query slots (160 KiB, all of it).
 //
 // Structure (512 threads = 8 waves, 2(M) x 4(N), two waves per SIMD, <= 256 registers):
-//   * two 64 KiB LDS stages [A 256 rows | B 256 rows] x 128 B, chunk-swizzled as before;
-//     every wave stages 8 KiB per K-step with 8 global_load_lds_dwordx4; the 12 K-steps of a
-//     tile are unrolled, so stage parity, K offsets and the first step's zero accumulator
-//     (MFMA with C = 0: no 128-register clear per tile) are compile-time;
-//   * ONE block barrier per K-step, placed before the last of its four k16 sub-steps:
-//     it certifies both that the next stage has landed (each wave waits for its own
-//     loads first) and that everybody's reads of the current stage have returned, so the
-//     current buffer is refilled for step+2 right behind it — a full step of flight time;
-//   * fragments are double-buffered in registers: the reads of sub-step j+1 (across the
-//     stage boundary too) are issued before the MFMAs of sub-step j, so no MFMA waits on LDS;
-//   * epilogue: VALU time is what it costs (two waves share a SIMD and reach it together), so
-//     it is a max tree: per 32x32 block the lane's 16 scores reduce to four group maxima and
-//     one block maximum; one ballot per block, then one per hot group of four, and only those
-//     four scores are examined.  Hits go to a per-wave LDS queue (three ds_write_b32) and are
-//     moved to the candidate buffers 64 at a time, so the returning global atomic that
-//     reserves a slot is paid per drain, not per hit.
+//   * step t multiplies corpus slot t%3 by query slot t%2; the 12 K-steps of a tile are
+//     unrolled (slots, the first step's C = 0 instead of a 128-register clear: compile-time);
+//   * ONE block barrier per K-step, before the last of its four k16 sub-steps.  Each wave first
+//     waits until only its newest 4 loads (corpus stage t+2, issued in this step) are
+//     outstanding, so the barrier certifies that stage t+1 has landed and that everybody's reads
+//     of stage t have returned; behind it the wave refills the query slot just released (stage
+//     t+2); the corpus slot released there is refilled (stage t+3) in the next step's first
+//     sub-step.  Issue order B(t+1), A(t+2), B(t+2), A(t+3) ... makes the counted wait exact;
+//   * fragments are double-buffered in registers: the reads of sub-step j+1 (across the stage
+//     boundary too) are issued between the MFMAs of sub-step j, so no MFMA waits on LDS;
+//   * epilogue: VALU time is what it costs (two waves share a SIMD and reach it together), so it
+//     is a max tree: per 32x32 block the lane's 16 scores reduce to four group maxima and one
+//     block maximum; one ballot per block, then one per hot group of four, and only those four
+//     scores are examined.  A hit waits in its lane's registers until some lane needs a second
+//     place; then all waiting hits reserve their slots at once (one atomic round trip per ~10
+//     hits of the wave, not per hit).
+//
+// Where the time goes (10M x 768, B = 1024, final pass; rocprofv3 PMC, cycles per K-step and CU):
+// MFMA alone 2100 (97 % of the matrix pipe, 2.0 GHz), staging alone 2580 (25 B/clk/CU through the
+// texture path: the binding rate is in shader clocks), both 2920 at ~1.7 GHz.  The kernel is
+// bound by operand delivery into LDS, 13 % above that floor.
 // Thresholds, append buffers, exactness argument and fallback are those of scan_mfma3.h.
 #pragma once
 #include <type_traits>
@@ -34,21 +45,23 @@
 namespace vdbk {
 
 constexpr int kM5BN = 256;                          // queries per block
-constexpr int kM5StageA = kMfBM * kMfBK * 2;        // 32 KiB
-constexpr int kM5StageB = kM5BN * kMfBK * 2;        // 32 KiB
-constexpr int kM5Stage = kM5StageA + kM5StageB;     // 64 KiB
-constexpr int kM5NumStages = 2;
+constexpr int kM5Slot = kMfBM * kMfBK * 2;          // 32 KiB: 256 rows x 128 B, either operand
+constexpr int kM5SlotsA = 3;
+constexpr int kM5SlotsB = 2;
+constexpr int kM5BaseB = kM5SlotsA * kM5Slot;
 constexpr int kM5Threads = 512;
+static_assert(kM5BN == kMfBM, "one set of staging offsets serves both operands");
 
-__host__ __device__ constexpr size_t m5_smem_bytes() { return (size_t)kM5NumStages * kM5Stage + 8 * 256 * 12; }   // + per-wave hit queues
+__host__ __device__ constexpr size_t m5_smem_bytes() { return (size_t)(kM5SlotsA + kM5SlotsB) * kM5Slot; }   // 160 KiB
 
-template <int MODE, int LP>
+template <int MODE, int ABL = 0>   // ABL (diagnostic, results invalid): 1 = no staging loads, 2 = no fragment reads / MFMAs,
+                                   // 3 = in-kernel cycle stamps (per wave: load wait, barrier wait, rest) written to `dense`
 __global__ __launch_bounds__(kM5Threads) void scan_mfma_wide_kernel(
     const unsigned char* __restrict__ rows, int n_rows, const unsigned char* __restrict__ qb16, int b, int n_qtiles,
     int n_splits, int tiles_per_split, int n_pass_tiles, int tile_stride, int self0, int xcd_map,
     const float* __restrict__ thr_in, float* __restrict__ dense, int* __restrict__ cand_cnt,
     float* __restrict__ cand_s, int* __restrict__ cand_i, int cap, int ablate) {
-  extern __shared__ __align__(16) unsigned char smem[];   // the only LDS object: 2 stages + 8 hit queues
+  extern __shared__ __align__(16) unsigned char smem[];   // the only LDS object: 3 corpus + 2 query slots
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -91,39 +104,49 @@ __global__ __launch_bounds__(kM5Threads) void scan_mfma_wide_kernel(
   const size_t tile_bytes = (size_t)tile_stride * (kMfBM * kMfRowBytes);
   const unsigned char* ta = rows + (size_t)tile0 * tile_bytes;   // corpus tile being multiplied
   const unsigned char* tn = my_tiles > 1 ? ta + tile_bytes : ta; // the one after it (the last tile names itself:
-                                                                 // its two trailing stage loads land in buffers nobody reads)
-  // piece i (0..3 corpus, 4..7 queries; 1 KiB per wave) of stage s_abs = K-step index counted from
-  // the current tile's first (12, 13 = the next tile's first two); 12 is even, so parity = buffer
-  // `partner`: the same piece of the wave that shares this wave's SIMD (w ^ 4: 32 rows further on or back)
-  const long long pd_g = wm == 0 ? 32 * kMfRowBytes : -32 * kMfRowBytes;
-  const int pd_l = wm == 0 ? 4096 : -4096;
-  auto piece = [&](int i, int s_abs, bool partner) {
+                                                                 // its trailing stage loads land in slots nobody reads)
+  // This wave's four 1 KiB pieces of a stage.  s_abs = K-step index counted from the current
+  // tile's first (12..14 = the next tile's first three).
+  auto stage_a = [&](int slot, int s_abs, int i0, int i1) {
+    if (ABL == 1) return;
     const bool wrap = s_abs >= kMfSteps;
-    const long long koff = (wrap ? s_abs - kMfSteps : s_abs) * (kMfBK * 2) + (partner ? pd_g : 0);
-    unsigned char* st = smem + (s_abs & 1) * kM5Stage + wbase16 + (partner ? pd_l : 0);
-    if (i < 4) mf_glds16((wrap ? tn : ta) + koff + g_off[i], st + i * (kM5Threads * 16));
-    else mf_glds16(qblk + koff + g_off[i - 4], st + kM5StageA + (i - 4) * (kM5Threads * 16));
+    const unsigned char* src = (wrap ? tn : ta) + (wrap ? s_abs - kMfSteps : s_abs) * (kMfBK * 2);
+    unsigned char* st = smem + slot * kM5Slot + wbase16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (i >= i0 && i < i1) mf_glds16(src + g_off[i], st + i * (kM5Threads * 16));
+  };
+  auto stage_b = [&](int slot, int s_abs, int i0, int i1) {
+    if (ABL == 1) return;
+    const unsigned char* src = qblk + (s_abs >= kMfSteps ? s_abs - kMfSteps : s_abs) * (kMfBK * 2);
+    unsigned char* st = smem + kM5BaseB + slot * kM5Slot + wbase16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (i >= i0 && i < i1) mf_glds16(src + g_off[i], st + i * (kM5Threads * 16));
   };
 
   // fragment reads: k16 sub-step s uses chunk 2s+hsel of rows (lane&31) + 32*block
   const int swz = ((lane & 31) >> 1) & 7;
   const int a_row_off = (wm * 128 + (lane & 31)) * 128;
-  const int b_row_off = kM5StageA + (wn * 64 + (lane & 31)) * 128;
+  const int b_row_off = kM5BaseB + (wn * 64 + (lane & 31)) * 128;
   int ck[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) ck[s] = ((2 * s + hsel) ^ swz) << 4;
 
   bf16x8_t fA[2][4], fB[2][2];
-  auto read_frags = [&](int fbuf, int stage_buf, int s) {
-    const unsigned char* sb = smem + stage_buf * kM5Stage;
+  auto read_frags = [&](int fbuf, int aslot, int bslot, int s) {
+    if (ABL == 2) return;
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) fA[fbuf][mt] = *reinterpret_cast<const bf16x8_t*>(sb + a_row_off + ck[s] + mt * 4096);
+    for (int mt = 0; mt < 4; ++mt)
+      fA[fbuf][mt] = *reinterpret_cast<const bf16x8_t*>(smem + aslot * kM5Slot + a_row_off + ck[s] + mt * 4096);
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) fB[fbuf][nt] = *reinterpret_cast<const bf16x8_t*>(sb + b_row_off + ck[s] + nt * 4096);
+    for (int nt = 0; nt < 2; ++nt)
+      fB[fbuf][nt] = *reinterpret_cast<const bf16x8_t*>(smem + bslot * kM5Slot + b_row_off + ck[s] + nt * 4096);
   };
 
   f32x16_t acc[4][2];
   auto mfma8 = [&](int fbuf, bool first) {
+    if (ABL == 2) return;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -136,102 +159,116 @@ __global__ __launch_bounds__(kM5Threads) void scan_mfma_wide_kernel(
         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fA[fbuf][mt], fB[fbuf][nt], c, 0, 0, 0);
       }
   };
-  // one k16 sub-step = 8 MFMAs; between them go the next sub-step's 6 fragment reads and NV staging loads
-  auto pin_schedule = [&](auto nv_tag) {
-    constexpr int NV = decltype(nv_tag)::value;
+  // one k16 sub-step = 8 MFMAs; between them go the next sub-step's 6 fragment reads and, behind the
+  // barrier, the step's 8 staging loads
+  auto pin_schedule = [&](int nv) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       // 1 MFMA
-      if (i < 6) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);            // 1 DS read
-      const int nv = ((i + 1) * NV) / 8 - (i * NV) / 8;                        // VMEM (LDS-DMA) after this MFMA
-      if (nv == 1) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-      if (nv == 2) __builtin_amdgcn_sched_group_barrier(0x010, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                            // 1 MFMA
+      if (i < 6) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                 // 1 DS read
+      if ((nv == 4 && (i & 1)) || (nv == 3 && (i == 1 || i == 4 || i == 7)) || (nv == 2 && (i == 3 || i == 7)) || (nv == 1 && i == 5))
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);                          // 1 VMEM (LDS-DMA)
     }
   };
-  using NV0 = std::integral_constant<int, 0>;
 
-  // per-wave hit queue in LDS, behind the two stages
-  constexpr int kQCap = 256;
-  float* q_s = reinterpret_cast<float*>(smem + kM5NumStages * kM5Stage + w * (kQCap * 12));
-  int* q_r = reinterpret_cast<int*>(q_s + kQCap);
-  int* q_q = q_r + kQCap;
-  int qn = 0;   // wave-uniform
-  auto drain = [&]() {
-    for (int base = 0; base < qn; base += 64) {
-      const int i = base + lane;
-      if (i < qn) {
-        const float s = q_s[i];
-        const int r = q_r[i], q = q_q[i];
-        const int pos = atomicAdd(&cand_cnt[q], 1);
-        if (pos < cap) { cand_s[(size_t)q * cap + pos] = s; cand_i[(size_t)q * cap + pos] = r; }
-      }
-    }
-    qn = 0;
-  };
-
-  // prologue: stage 0 lands, stage 1 starts, sub-step 0 fragments of stage 0 are read
-#pragma unroll
-  for (int i = 0; i < 8; ++i) piece(i, 0, false);
+  // prologue: stage 0 lands; stage 1 and the corpus half of stage 2 go out; sub-step 0 fragments are read
+  stage_b(0, 0, 0, 4);
+  stage_a(0, 0, 0, 4);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-#pragma unroll
-  for (int i = 0; i < 8; ++i) piece(i, 1, false);
-  read_frags(0, 0, 0);
+  stage_b(1, 1, 0, 4);
+  stage_a(1, 1, 0, 4);
+  read_frags(0, 0, 0, 0);
 
-  // one K-step; the stage parity `buf` and `first` (first step of a tile: C = 0) are compile-time,
-  // the K-step index ks is a scalar
-  auto step = [&](auto buf_tag, auto first_tag, int ks) {
-    constexpr int buf = decltype(buf_tag)::value;
+  // A hit waits in its lane's registers (one place per lane) until some lane needs a second place; then
+  // every waiting hit reserves its slot in its query's candidate buffer at once.  The returning atomic
+  // (~1 us, and its s_waitcnt drains the staged loads in flight too) is thus paid once per ~10 hits of
+  // the wave instead of once per hit.
+  float pend_v = 0.f;
+  int pend_row = 0, pend_q = 0;
+  bool pend_has = false;
+  auto flush_pending = [&]() {
+    if (pend_has) {
+      const int pos = atomicAdd(&cand_cnt[pend_q], 1);
+      if (pos < cap) { cand_s[(size_t)pend_q * cap + pos] = pend_v; cand_i[(size_t)pend_q * cap + pos] = pend_row; }
+    }
+    pend_has = false;
+  };
+  unsigned long long prof_a = 0, prof_b = 0, prof_c = 0, prof_d = 0, prof_last = 0;
+  int prof_n = 0;
+  // one K-step on corpus slot AS and query slot BS (compile-time); ks is a scalar
+  auto step = [&](auto as_tag, auto bs_tag, auto first_tag, int ks) {
+    // keep ks opaque: as a literal it is folded into forty-odd per-lane 64-bit source offsets that spill
+    asm volatile("" : "+s"(ks));
+    constexpr int AS = decltype(as_tag)::value;
+    constexpr int BS = decltype(bs_tag)::value;
     constexpr bool first = decltype(first_tag)::value != 0;
-    read_frags(1, buf, 1);
+    // Staging loads are spread.  The texture addresser takes one LDS-DMA instruction per ~20 cycles per CU
+    // and the issuing wave waits its turn: eight waves issuing eight each right behind the barrier stood
+    // ~1000 cycles per step in that queue with no MFMA issued (in-kernel stamps, ABL = 3).  So: the corpus
+    // stage ks+2 here, one load per two MFMAs of sub-step 0 (its slot was released at the previous barrier
+    // and it is needed only at the barrier after next); the query stage ks+2 behind this step's barrier.
+    // Other placements (2+2 over two sub-steps, sub-step 1, 3/2/1/2) measured the same or worse.
+    constexpr int A2 = (AS + 2) % kM5SlotsA;   // the corpus slot released at the previous step's barrier
+    read_frags(1, AS, BS, 1);
+    stage_a(A2, ks + 2, 0, 4);
     mfma8(0, first);
-    pin_schedule(NV0{});
-    read_frags(0, buf, 2);
+    pin_schedule(4);
+    read_frags(0, AS, BS, 2);
     mfma8(1, false);
-    pin_schedule(NV0{});
-    read_frags(1, buf, 3);
+    pin_schedule(0);
+    read_frags(1, AS, BS, 3);
     mfma8(0, false);
-    pin_schedule(NV0{});
-    // every read of this stage has returned and my share of the next stage has landed -> barrier
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    pin_schedule(0);
+    unsigned long long t1 = 0, t2 = 0;
+    if (ABL == 3) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); t1 = __builtin_readcyclecounter(); }
+    // all but my newest four loads (corpus stage ks+2, issued in this step) have landed, every read of
+    // this stage has returned.
+    // (The first step of a tile follows an epilogue whose stores and atomics share the counter and may
+    // complete out of order with the loads: there the count proves nothing, so it drains to zero.)
+    if (first) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    if (ABL == 3) t2 = __builtin_readcyclecounter();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    // Refill the buffer just released, for step+2, and read the first fragments of the next stage.
-    // An LDS-DMA instruction holds its wave's issue slot ~100 cycles while the L2->LDS path is busy,
-    // and a wave stuck there issues no MFMAs.  With LP > 8 the two waves of a SIMD (w, w^4) take
-    // turns: this step's loader issues LP of the pair's 16 pieces, its partner the other 16-LP, so
-    // one of them keeps the matrix pipe fed while the other feeds the memory pipe.
-    if (LP == 8) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) piece(j, ks + 2, false);
-      read_frags(0, buf ^ 1, 0);
-      mfma8(1, false);
-      pin_schedule(std::integral_constant<int, 8>{});
-    } else {
-      // (the branch holds only the loads: MFMAs inside it would make hipcc copy the accumulators at the join)
-      if (wm == buf) {
-#pragma unroll
-        for (int j = 0; j < LP; ++j) piece(j & 7, ks + 2, j >= 8);
-      } else {
-#pragma unroll
-        for (int j = LP - 8; j < 8; ++j) piece(j, ks + 2, false);
-      }
-      read_frags(0, buf ^ 1, 0);
-      mfma8(1, false);
-      pin_schedule(NV0{});
+    if (ABL == 3) {
+      const unsigned long long t3 = __builtin_readcyclecounter();
+      if (prof_last) prof_c += t1 - prof_last;
+      prof_a += t2 - t1;
+      prof_b += t3 - t2;
+      prof_last = t3;
+      ++prof_n;
     }
+    stage_b(BS, ks + 2, 0, 4);                // the query slot just released
+    if (ABL == 3) {
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long t4 = __builtin_readcyclecounter();
+      asm volatile("" :: "s"(t4));
+      prof_d += t4 - prof_last;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    read_frags(0, (AS + 1) % kM5SlotsA, BS ^ 1, 0);   // first fragments of the next stage
+    mfma8(1, false);
+    pin_schedule(4);
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
 
   for (int tile = 0; tile < my_tiles; ++tile) {
-    step(I0{}, I1{}, 0);
-    step(I1{}, I0{}, 1);
-    for (int ks = 2; ks < kMfSteps; ks += 2) {
-      step(I0{}, I0{}, ks);
-      step(I1{}, I0{}, ks + 1);
-    }
+    step(I0{}, I0{}, I1{}, 0);
+    step(I1{}, I1{}, I0{}, 1);
+    step(I2{}, I0{}, I0{}, 2);
+    step(I0{}, I1{}, I0{}, 3);
+    step(I1{}, I0{}, I0{}, 4);
+    step(I2{}, I1{}, I0{}, 5);
+    step(I0{}, I0{}, I0{}, 6);
+    step(I1{}, I1{}, I0{}, 7);
+    step(I2{}, I0{}, I0{}, 8);
+    step(I0{}, I1{}, I0{}, 9);
+    step(I1{}, I0{}, I0{}, 10);
+    step(I2{}, I1{}, I0{}, 11);
     ta = tn;
     if (tile + 2 < my_tiles) tn += tile_bytes;
     if (ablate & 4) continue;   // ablate bit 2: no epilogue (diagnostic, results invalid)
@@ -269,23 +306,22 @@ __global__ __launch_bounds__(kM5Threads) void scan_mfma_wide_kernel(
                 const int row = (int)tile_row0 + rbase + e + 8 * g;   // register 4g+e holds tile row rbase + e + 8g
                 bool pass = v >= thr[nt];
                 if (needs_mask) pass = pass && (row < n_rows) && (qg < b) && !(self0 >= 0 && row == self0 + qg);
-                const unsigned long long pb = __ballot(pass);
-                if (pb != 0ull) {
-                  if (qn > kQCap - 64) drain();
-                  const int slot = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(pb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)pb, 0u));
-                  if (pass) { q_s[slot] = v; q_r[slot] = row; q_q[slot] = qg; }
-                  qn += __popcll(pb);
-                }
+                if (__ballot(pass) == 0ull) continue;
+                if (__ballot(pass && pend_has) != 0ull) flush_pending();   // a lane would need a second place
+                if (pass) { pend_v = v; pend_row = row; pend_q = qg; pend_has = true; }
               }
             }
           }
         }
       }
     }
-    if (MODE == 1 && qn >= kQCap / 2) drain();
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing (unused) staging loads
-  if (MODE == 1) drain();
+  if (MODE == 1) flush_pending();
+  if (ABL == 3 && lane == 0) {
+    float* o = dense + (size_t)(blockIdx.x * 8 + w) * 4;
+    o[0] = (float)prof_a; o[1] = (float)prof_b; o[2] = (float)prof_c; o[3] = (float)prof_d;
+  }
 }
 
 }  // namespace vdbk

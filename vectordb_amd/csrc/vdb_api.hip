@@ -52,7 +52,6 @@ struct vdb {
   DevBuf w_q, w_part_s, w_part_i, w_part2_s, w_part2_i, w_stage, w_out_i, w_out_d, w_idx, w_mfma;
   DevBuf w_cand_s, w_cand_i, w_cand_cnt, w_thr, w_dense, w_list_s, w_list_i;   // append-path state
   int mfma_append_cap = 16384;   // candidate buffer entries per query
-  int mfma_stage_dist = 8;       // wide kernel: staging loads per step issued by the loader wave of a SIMD pair (8 = each its own)
   int mfma_variant = 5;          // 3 = barrier ring (scan_mfma3.h), 4 = warp-specialised (scan_mfma4.h),
                                  // 5 = 256x256 tile (scan_mfma5.h) when that pads the batch no further, else 4
   int mfma_last_b = 0;           // batch size of the last MFMA search (locates its overflow flag)
@@ -302,10 +301,11 @@ int mfma_search(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
     HIP_TRY(h, hipFuncSetAttribute((const void*)scan_mfma_pass_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kMfNumStages * kMfStage));
     HIP_TRY(h, hipFuncSetAttribute((const void*)scan_mfma_ws_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_smem_bytes()));
     HIP_TRY(h, hipFuncSetAttribute((const void*)scan_mfma_ws_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_smem_bytes()));
-    HIP_TRY(h, hipFuncSetAttribute((const void*)scan_mfma_wide_kernel<0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m5_smem_bytes()));
-    HIP_TRY(h, hipFuncSetAttribute((const void*)scan_mfma_wide_kernel<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m5_smem_bytes()));
-    HIP_TRY(h, hipFuncSetAttribute((const void*)scan_mfma_wide_kernel<1, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m5_smem_bytes()));
-    HIP_TRY(h, hipFuncSetAttribute((const void*)scan_mfma_wide_kernel<1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m5_smem_bytes()));
+    HIP_TRY(h, hipFuncSetAttribute((const void*)scan_mfma_wide_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m5_smem_bytes()));
+    HIP_TRY(h, hipFuncSetAttribute((const void*)scan_mfma_wide_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m5_smem_bytes()));
+    HIP_TRY(h, hipFuncSetAttribute((const void*)scan_mfma_wide_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m5_smem_bytes()));
+    HIP_TRY(h, hipFuncSetAttribute((const void*)scan_mfma_wide_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m5_smem_bytes()));
+    HIP_TRY(h, hipFuncSetAttribute((const void*)scan_mfma_wide_kernel<1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m5_smem_bytes()));
     attr_set = true;
   }
   const unsigned char* qb16 = (const unsigned char*)h->w_mfma.p;
@@ -332,7 +332,7 @@ int mfma_search(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
     const int stride = (int)std::max<long long>(1, n_tiles / t_cur);
     const MfGrid g = mf_grid(h->n_cu, n_qt, t_cur, 1 << 30);
     if (variant == 5)
-      hipLaunchKernelGGL((scan_mfma_wide_kernel<0, 8>), dim3(n_qt * g.n_splits), dim3(kM5Threads), m5_smem_bytes(), st, rows, n_rows, qb16, b,
+      hipLaunchKernelGGL((scan_mfma_wide_kernel<0>), dim3(n_qt * g.n_splits), dim3(kM5Threads), m5_smem_bytes(), st, rows, n_rows, qb16, b,
                          n_qt, g.n_splits, g.tiles_per_split, (int)t_cur, stride, self0, g.xcd_map, (const float*)nullptr, dense,
                          (int*)nullptr, (float*)nullptr, (int*)nullptr, 0, 0);
     else if (variant == 4)
@@ -361,7 +361,7 @@ int mfma_search(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
     HIP_TRY(h, hipMemsetAsync(cand_cnt, 0, (size_t)b * 4, st));
     const MfGrid g = mf_grid(h->n_cu, n_qt, t_next, 1 << 30);
     if (variant == 5) {
-      auto kern = h->mfma_stage_dist == 16 ? scan_mfma_wide_kernel<1, 16> : h->mfma_stage_dist == 12 ? scan_mfma_wide_kernel<1, 12> : scan_mfma_wide_kernel<1, 8>;
+      auto kern = (h->mfma_ablate & 8) ? scan_mfma_wide_kernel<1, 3> : (h->mfma_ablate & 1) ? scan_mfma_wide_kernel<1, 1> : (h->mfma_ablate & 2) ? scan_mfma_wide_kernel<1, 2> : scan_mfma_wide_kernel<1, 0>;
       hipLaunchKernelGGL(kern, dim3(n_qt * g.n_splits), dim3(kM5Threads), m5_smem_bytes(), st, rows, n_rows, qb16, b,
                          n_qt, g.n_splits, g.tiles_per_split, (int)t_next, stride, self0, g.xcd_map, (const float*)thr, dense,
                          cand_cnt, cand_s, cand_i, cap, h->mfma_ablate);
@@ -845,10 +845,6 @@ int vdb_set_option(vdb_t* h, const char* name, int64_t value) {
   }
   if (!strcmp(name, "scan_nt_loads")) { h->scan_nt_loads = value != 0; return VDB_OK; }
   if (!strcmp(name, "mfma_ablate")) { h->mfma_ablate = (int)value; return VDB_OK; }
-  if (!strcmp(name, "mfma_stage_dist")) {
-    if (value != 8 && value != 12 && value != 16) return fail(h, VDB_ERR_ARG, "mfma_stage_dist must be 8, 12 or 16");
-    h->mfma_stage_dist = (int)value; return VDB_OK;
-  }
   if (!strcmp(name, "mfma_variant")) {
     if (value < 3 || value > 5) return fail(h, VDB_ERR_ARG, "mfma_variant must be 3, 4 or 5");
     h->mfma_variant = (int)value; return VDB_OK;
@@ -875,6 +871,19 @@ int vdb_get_stat(vdb_t* h, const char* name, int64_t* value) {
     HIP_TRY(h, hipDeviceSynchronize());
     HIP_TRY(h, hipMemcpy(&flag, (int*)h->w_cand_cnt.p + h->mfma_last_b, 4, hipMemcpyDeviceToHost));
     *value = flag != 0;
+    return VDB_OK;
+  }
+  if (!strncmp(name, "mfma_prof_", 10) && name[10] >= 'a' && name[10] <= 'd') {   // diagnostic: mean stamp totals of mfma_ablate=8
+    *value = 0;
+    if (!h->w_dense.p) return VDB_OK;
+    int rc = set_device(h);
+    if (rc) return rc;
+    std::vector<float> pr((size_t)h->n_cu * 8 * 4);
+    HIP_TRY(h, hipDeviceSynchronize());
+    HIP_TRY(h, hipMemcpy(pr.data(), h->w_dense.p, pr.size() * 4, hipMemcpyDeviceToHost));
+    double tot = 0;
+    for (size_t i = 0; i < pr.size() / 4; ++i) tot += pr[i * 4 + (name[10] - 'a')];
+    *value = (int64_t)(tot / (pr.size() / 4));
     return VDB_OK;
   }
   if (!strcmp(name, "mfma_last_hits")) {   // candidates appended by the last (full) pass, summed over queries
