@@ -153,8 +153,8 @@ def main():
     # sanity inside the bench: planted neighbour of the last batch is rank 1 and results ascend
     last = (args.steps - 1) % n_sets
     idx_h, dist_h = idx.cpu().numpy(), dd.cpu().numpy()
-    from oracle import oracle as _ora   # checker only
-    src = np.array([_ora.synth_query_src(qspec, last * b + j) for j in range(min(b, 8))])
+    from vectordb_amd.synth import query_source_row
+    src = np.array([query_source_row(qspec, last * b + j) for j in range(min(b, 8))])
     planted_ok = bool(np.array_equal(idx_h[: len(src), 0], src)) and bool(np.all(np.diff(dist_h, axis=1) >= 0))
 
     if rank == 0:
@@ -164,6 +164,11 @@ def main():
         if mfma:
             alg = 2.0 * b * n_local * dim
             roof = {"bound": "mfma", "achieved": alg / (scan_ms * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s"}
+            # operand bytes staged through LDS per batch: the path that actually binds the kernel
+            bn = 256 if ((b + 255) // 256) * 256 == ((b + 127) // 128) * 128 else 128
+            b_pad = ((b + bn - 1) // bn) * bn
+            roof["lds_staged_bytes"] = float(n_local) * dim * esz * b_pad * (1.0 / bn + 1.0 / 256)
+            roof["lds_staging_TBps"] = roof["lds_staged_bytes"] / (scan_ms * 1e-3) / 1e12
         else:
             alg = float(n_local) * dim * esz           # one corpus pass per launch
             roof = {"bound": "hbm", "achieved": alg / (scan_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s"}

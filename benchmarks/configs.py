@@ -46,8 +46,12 @@ def main():
     if "c1" in which:   # real-catalog size through the Chroma-shaped API (embeddings synthetic: SURVEY 8c)
         n = 14777
         spec = SynthSpec(seed=1234, kind=1, n_clusters=121, noise=0.3)
-        from oracle import oracle
-        rows = oracle.synth_rows(0, n, dim, spec)
+        gen = FlatIndex(dim, "f32", False)
+        rows_dev = torch.empty((n, dim), dtype=torch.float32, device="cuda")
+        gen.synth_rows_device(rows_dev.data_ptr(), 0, n, spec, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        rows = rows_dev.cpu().numpy()
+        gen.close()
         col = EphemeralClient().get_or_create_collection("actual_products", metadata={"hnsw:space": "cosine"})
         for lo in range(0, n, 5000):
             col.add(ids=[f"item_{i}" for i in range(lo, min(n, lo + 5000))], embeddings=rows[lo:lo + 5000],

@@ -92,3 +92,13 @@ def test_cpu_abi_store_roundtrip(oracle_lib, oracle_mod, tmp_path):
     with pytest.raises(Exception):
         ix.search(q, 5, 10)  # rerank on an f32 store
     ix.close()
+
+
+def test_query_source_row_host_mirror(oracle_mod):
+    """vectordb_amd.synth.query_source_row (pure Python, used by bench.py's sanity check) ==
+    the generator's own planted-neighbour index."""
+    from vectordb_amd import SynthSpec
+    from vectordb_amd.synth import query_source_row
+    q = SynthSpec(seed=1235, kind=2, noise=0.5, base_kind=1, base_seed=1234, base_n=10_000_000, base_n_clusters=3162, base_noise=0.3)
+    for i in list(range(64)) + [10 ** 9 + 7, 2 ** 40 + 3]:
+        assert query_source_row(q, i) == oracle_mod.synth_query_src(q, i)
