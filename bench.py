@@ -165,7 +165,7 @@ def main():
             alg = 2.0 * b * n_local * dim
             roof = {"bound": "mfma", "achieved": alg / (scan_ms * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s"}
             # operand bytes staged through LDS per batch: the path that actually binds the kernel
-            bn = 256 if ((b + 255) // 256) * 256 == ((b + 127) // 128) * 128 else 128
+            bn = 256 if 2 * (((b + 255) // 256) * 256) <= 3 * (((b + 127) // 128) * 128) else 128   # vdb_api.hip: mfma_search
             b_pad = ((b + bn - 1) // bn) * bn
             roof["lds_staged_bytes"] = float(n_local) * dim * esz * b_pad * (1.0 / bn + 1.0 / 256)
             roof["lds_staging_TBps"] = roof["lds_staged_bytes"] / (scan_ms * 1e-3) / 1e12
@@ -184,7 +184,7 @@ def main():
                 roof["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, separate pass)"
         except (OSError, KeyError, ValueError):
             pass
-        wide = mfma and ((b + 255) // 256) * 256 == ((b + 127) // 128) * 128
+        wide = mfma and 2 * (((b + 255) // 256) * 256) <= 3 * (((b + 127) // 128) * 128)
         roof["kernel"] = ("scan_mfma_wide_kernel<1> + sample passes" if wide else "scan_mfma_ws_kernel<1> + sample passes") if mfma else "scan_topk_kernel"
         roof["kernel_avg_ms"] = scan_ms
         roof["merge_rerank_avg_ms"] = tstats["merge_ms_sum"] / max(tstats["n"], 1)

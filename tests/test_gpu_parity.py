@@ -247,7 +247,7 @@ def test_million_rows_properties(hip_lib, oracle_mod):
 # ----------------------------------------------------------------------------
 # batched MFMA path (bf16 store, B >= 16)
 # ----------------------------------------------------------------------------
-@pytest.mark.parametrize("b", [16, 100, 128, 200, 256, 300, 512])   # 200/256/512 take the 256-wide tile, the rest the 128-wide
+@pytest.mark.parametrize("b", [16, 100, 128, 200, 256, 300, 512])   # 200/256/300/512 take the 256-wide tile, 16/100/128 the 128-wide
 def test_mfma_batch_parity(hip_lib, oracle_mod, corpus20k, b):
     """Q.D^T on MFMA + fused top-k' + fp32 rerank vs the exact oracle.  Every corpus
     tile's first pass overflows the LDS candidate queue (all scores beat -inf), so the
