@@ -64,7 +64,16 @@ def cpu_baseline(dim, k, target_rows, seed, budget_s=20.0):
     return {"value": qps_sample * scale, "unit": "queries/s", "cores": int(oracle.lib().ora_num_threads()), "kind": "port",
             "sample": f"{done} batch-1 queries over a {sample_rows}x{dim} fp32 sample of the corpus, exact top-{k}; "
                       f"QPS scaled by {sample_rows}/{target_rows} rows (linear scan)",
-            "numpy_sgemv_qps_scaled": np_qps * scale, "host_cpus": os.cpu_count()}
+            "numpy_sgemv_qps_scaled": np_qps * scale, "host_cpus": os.cpu_count(),
+            "chroma_baseline": _chroma_note()}
+
+
+def _chroma_note():
+    """the reference's own engine, if it can be imported on this box."""
+    import importlib.util
+    if importlib.util.find_spec("chromadb") is None:
+        return "Chroma baseline unavailable (chromadb is not installed here); the reference's only published figure is 0.011 s/query incl. embedding on its toy set (README.md:120)"
+    return "chromadb importable: not timed by this script"
 
 
 def main():
@@ -145,6 +154,15 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     tstats = sh.local.timing_stats()
+    # outside the timed region: per-call latency with a sync after every call (median and p99)
+    lat = []
+    for i in range(min(args.steps, 100)):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        step(i)
+        torch.cuda.synchronize()
+        lat.append((time.perf_counter() - t1) * 1e3)
+    lat = np.sort(np.asarray(lat))
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -173,6 +191,15 @@ def main():
             alg = float(n_local) * dim * esz           # one corpus pass per launch
             roof = {"bound": "hbm", "achieved": alg / (scan_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s"}
         roof["frac"] = roof["achieved"] / roof["peak"]
+        # the same ceilings as measured on this device (streaming read of the store; bare bf16 MFMA loop)
+        try:
+            if mfma:
+                roof["measured_peak"] = sh.local.get_stat("probe_mfma_bf16_gflops") / 1e3
+            else:
+                roof["measured_peak"] = sh.local.get_stat("probe_hbm_read_mbps") / 1e3
+            roof["frac_of_measured_peak"] = roof["achieved"] / roof["measured_peak"] if roof["measured_peak"] else None
+        except RuntimeError:
+            roof["measured_peak"] = None
         # HBM bytes per launch from a separate rocprofv3 --pmc FETCH_SIZE pass of this same command
         # (profiles/r01_pmc_traffic.json; gfx950 FETCH_SIZE correction applied there)
         roof["traffic"] = None
@@ -202,6 +229,7 @@ def main():
                        "mfma_overflow_fallback": sh.local.get_stat("mfma_last_overflow"),
                        "mfma_hits_per_query": sh.local.get_stat("mfma_last_hits") / b,
                        **({"prof": [sh.local.get_stat("mfma_prof_" + c) for c in "abcd"]} if args.ablate & 8 else {})},
+            "sync_latency_ms": {"median": float(np.median(lat)), "p99": float(lat[min(len(lat) - 1, int(0.99 * len(lat)))]), "calls": len(lat)},
             "build_s": t_build,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -63,3 +63,36 @@ def test_shard_range_covers_everything():
             spans = [shard_range(n, r, g) for r in range(g)]
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(spans[i][1] == spans[i + 1][0] for i in range(g - 1))
+
+
+def _sj_worker(rank, world, port, n, dim, k, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import oracle
+        from vectordb_amd import SynthSpec
+        from vectordb_amd.distributed import ReplicatedSelfJoin
+        sj = ReplicatedSelfJoin(dim, "bf16", True, device=torch.device("cpu"), lib=oracle.lib())
+        sj.add_synth(n, SynthSpec(seed=77, kind=1, n_clusters=17, noise=0.3))
+        lo, idx, dd = sj.selfjoin_partition(k, exclude_self=True, rerank_kprime=16)
+        np.savez(os.path.join(out_dir, f"sj{rank}.npz"), lo=lo, idx=idx, dist=dd)
+        sj.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_replicated_selfjoin_shards_tile_the_whole_join(tmp_path, oracle_mod):
+    """C5's multi-GPU form: corpus replicated, queries sharded, no collective — the ranks'
+    slices laid end to end are the single-process self-join."""
+    from vectordb_amd import FlatIndex, SynthSpec
+    n, dim, k, world = 503, 64, 4, 2
+    mp.spawn(_sj_worker, args=(world, _free_port(), n, dim, k, str(tmp_path)), nprocs=world, join=True)
+    whole = FlatIndex(dim, "bf16", True, lib=oracle_mod.lib())
+    whole.add_synth(0, n, SynthSpec(seed=77, kind=1, n_clusters=17, noise=0.3))
+    ref_idx, ref_dist = whole.selfjoin(k, exclude_self=True, rerank_kprime=16)
+    whole.close()
+    parts = [np.load(tmp_path / f"sj{r}.npz") for r in range(world)]
+    assert [int(p["lo"]) for p in parts] == [0, 252]
+    assert np.array_equal(np.concatenate([p["idx"] for p in parts]), ref_idx)
+    assert np.array_equal(np.concatenate([p["dist"] for p in parts]), ref_dist)
+    assert not np.any(ref_idx == np.arange(n)[:, None])

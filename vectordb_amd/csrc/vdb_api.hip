@@ -17,6 +17,7 @@
 #include "synth.h"
 #include "scan_mfma4.h"
 #include "scan_mfma5.h"
+#include "probes.h"
 
 using namespace vdbk;
 
@@ -886,6 +887,42 @@ int vdb_get_stat(vdb_t* h, const char* name, int64_t* value) {
     double tot = 0;
     for (size_t i = 0; i < pr.size() / 4; ++i) tot += pr[i * 4 + (name[10] - 'a')];
     *value = (int64_t)(tot / (pr.size() / 4));
+    return VDB_OK;
+  }
+  if (!strcmp(name, "probe_hbm_read_mbps") || !strcmp(name, "probe_mfma_bf16_gflops")) {
+    // measured ceilings of this device; a few milliseconds each, best of 3
+    int rc = set_device(h);
+    if (rc) return rc;
+    if ((rc = ensure(h, h->w_thr, 64))) return rc;
+    hipEvent_t e0, e1;
+    HIP_TRY(h, hipEventCreate(&e0));
+    HIP_TRY(h, hipEventCreate(&e1));
+    const bool rd = name[6] == 'h';
+    const void* src = h->dtype == VDB_BF16 ? (const void*)h->rows_bf16 : (const void*)h->rows_f32;
+    const size_t bytes = (size_t)h->n * h->ld * (h->dtype == VDB_BF16 ? 2 : 4);
+    if (rd && (!src || bytes < ((size_t)64 << 20))) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return fail(h, VDB_ERR_ARG, "probe_hbm_read_mbps needs a store of at least 64 MiB to stream"); }
+    const int iters = 40000;
+    double best = 0.0;
+    for (int rep = 0; rep < (rd ? 9 : 4); ++rep) {
+      HIP_TRY(h, hipEventRecord(e0, h->stream));
+      // read probe: best over {4, 8} blocks per CU x {4, 8, 12} loads in flight per lane (+ a warm-up launch)
+      const int gm = (rep & 1) ? 8 : 4, u = ((rep + 1) / 2) % 3;
+      if (rd && u == 0) hipLaunchKernelGGL((probe_read_kernel<4>), dim3(h->n_cu * gm), dim3(256), 0, h->stream, (const v4u_t*)src, bytes / 16, (unsigned*)h->w_thr.p);
+      else if (rd && u == 1) hipLaunchKernelGGL((probe_read_kernel<8>), dim3(h->n_cu * gm), dim3(256), 0, h->stream, (const v4u_t*)src, bytes / 16, (unsigned*)h->w_thr.p);
+      else if (rd) hipLaunchKernelGGL((probe_read_kernel<12>), dim3(h->n_cu * gm), dim3(256), 0, h->stream, (const v4u_t*)src, bytes / 16, (unsigned*)h->w_thr.p);
+      else hipLaunchKernelGGL(probe_mfma_kernel, dim3(h->n_cu), dim3(512), 0, h->stream, iters, (float*)h->w_thr.p);
+      HIP_TRY(h, hipGetLastError());
+      HIP_TRY(h, hipEventRecord(e1, h->stream));
+      HIP_TRY(h, hipEventSynchronize(e1));
+      float ms = 0.f;
+      HIP_TRY(h, hipEventElapsedTime(&ms, e0, e1));
+      if (rep == 0 || ms <= 0.f) continue;   // first launch warms up
+      const double v = rd ? (double)bytes / (ms * 1e-3) / 1e6 : (double)h->n_cu * 8 * iters * 8 * 32768.0 / (ms * 1e-3) / 1e9;
+      best = std::max(best, v);
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *value = (int64_t)best;
     return VDB_OK;
   }
   if (!strcmp(name, "mfma_last_hits")) {   // candidates appended by the last (full) pass, summed over queries

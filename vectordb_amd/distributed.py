@@ -91,3 +91,34 @@ class ShardedIndex:
 
     def close(self) -> None:
         self.local.close()
+
+
+class ReplicatedSelfJoin:
+    """All-pairs neighbours of a corpus small enough to replicate (SURVEY.md 8e, C5:
+    2M x 768 bf16 + fp32 = 9.2 GB per GPU): every rank holds the WHOLE corpus and
+    joins its contiguous slice of the rows-as-queries against it.  The shards are
+    independent — no collective on the data path; a caller that wants the whole
+    result on one rank gathers the [n, k] outputs itself."""
+
+    def __init__(self, dim: int, dtype: str = "bf16", keep_f32_for_rerank: bool = True, *,
+                 device: Optional[torch.device] = None, group=None, lib=None):
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        device = torch.device(device) if device is not None else torch.device("cpu")
+        dev_index = device.index if device.type == "cuda" and device.index is not None else 0
+        self.local = FlatIndex(dim, dtype, keep_f32_for_rerank, dev_index, lib=lib)
+
+    def add(self, rows) -> None:
+        self.local.add(rows)
+
+    def add_synth(self, n: int, spec: SynthSpec) -> None:
+        self.local.add_synth(0, n, spec)
+
+    def selfjoin_partition(self, k: int, exclude_self: bool = True, rerank_kprime: int = 0):
+        """-> (lo, idx [hi-lo, k] int64, dist [hi-lo, k] fp32): neighbours of rows [lo, hi), this rank's share."""
+        lo, hi = shard_range(self.local.count(), self.rank, self.world)
+        idx, dd = self.local.selfjoin(k, exclude_self=exclude_self, rerank_kprime=rerank_kprime, q_row0=lo, q_n=hi - lo)
+        return lo, idx, dd
+
+    def close(self) -> None:
+        self.local.close()
