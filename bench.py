@@ -92,6 +92,9 @@ def main():
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--nt", type=int, default=-1)
     ap.add_argument("--mfma-variant", type=int, default=0)
+    ap.add_argument("--force-collective", action="store_true",
+                    help="diagnostic, 1 GPU: run the all-gather + merge exchange with a single-rank RCCL group")
+    ap.add_argument("--sync-exchange", action="store_true", help="diagnostic: wait for each batch's exchange (no overlap)")
     ap.add_argument("--clusters", type=int, default=0, help="synthetic clusters (default sqrt(rows))")
     ap.add_argument("--ablate", type=int, default=0, help="diagnostic: MFMA kernel ablation bits (results invalid)")
     args = ap.parse_args()
@@ -107,6 +110,8 @@ def main():
     device = torch.device("cuda", local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=device)
+    elif args.force_collective:
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29631", rank=0, world_size=1, device_id=device)
 
     kp = args.kprime if args.dtype == "bf16" else 0
     n, dim, b, k = args.rows, args.dim, args.batch, args.k
@@ -115,7 +120,7 @@ def main():
                       base_n_clusters=spec.n_clusters, base_noise=0.3)
 
     t_build = time.perf_counter()
-    sh = ShardedIndex(dim, args.dtype, True, device=device)
+    sh = ShardedIndex(dim, args.dtype, True, device=device, force_collective=args.force_collective)
     sh.add_synth_partition(n, spec)
     lo, hi = shard_range(n, rank, world)
     n_local = hi - lo
@@ -136,7 +141,9 @@ def main():
     t_build = time.perf_counter() - t_build
 
     def step(i):
-        return sh.search(qpool[i % n_sets], k, kp)
+        # throughput mode: the exchange of batch i (side stream) overlaps the scan of batch i+1;
+        # every batch's exchange and merge still complete inside the timed region (device sync)
+        return sh.search(qpool[i % n_sets], k, kp, wait=args.sync_exchange)
 
     for i in range(args.warmup):
         step(i)
@@ -160,7 +167,7 @@ def main():
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         step(i)
-        torch.cuda.synchronize()
+        torch.cuda.synchronize()   # waits for the side stream too: full per-call latency incl. the exchange
         lat.append((time.perf_counter() - t1) * 1e3)
     lat = np.sort(np.asarray(lat))
     if world > 1:
@@ -169,7 +176,10 @@ def main():
         elapsed = float(t.item())
 
     # sanity inside the bench: planted neighbour of the last batch is rank 1 and results ascend
+    # (a fresh call: the tensors the timed loop returned are ring buffers the latency loop has reused since)
     last = (args.steps - 1) % n_sets
+    idx, dd = sh.search(qpool[last], k, kp)
+    torch.cuda.synchronize()
     idx_h, dist_h = idx.cpu().numpy(), dd.cpu().numpy()
     from vectordb_amd.synth import query_source_row
     src = np.array([query_source_row(qspec, last * b + j) for j in range(min(b, 8))])
@@ -236,7 +246,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(dim, k, n, args.seed)
         print(json.dumps(out), flush=True)
     sh.close()
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -416,3 +416,46 @@ def test_packed_allgather_layout_merge(hip_lib, oracle_mod, corpus20k):
     r_idx, r_dist, r_sc = oracle_mod.exact_topk(rows, queries, k)
     check_topk(w_idx.cpu().numpy(), w_dist.cpu().numpy(), r_idx, r_dist, r_sc, rows, _qn(oracle_mod, queries), what="sharded world=1")
     sh.close()
+
+
+def test_sharded_exchange_on_side_stream(hip_lib, oracle_mod, corpus20k):
+    """The N>1 code path on one GPU: RCCL with a single rank, exchange forced on.  The
+    all-gather + merge run on the side stream; wait=False results are valid after
+    wait_results(), buffer sets are recycled every second call, and every answer equals
+    the plain single-index answer."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from vectordb_amd.distributed import ShardedIndex
+    n, dim, spec, rows, _ = corpus20k
+    qspec = SynthSpec(seed=2024, kind=2, noise=0.5, base_kind=1, base_seed=1234, base_n=n, base_n_clusters=141, base_noise=0.3)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        sh = ShardedIndex(dim, "bf16", True, device=torch.device("cuda", 0), force_collective=True)
+        sh.add_synth_partition(n, spec)
+        plain = FlatIndex(dim, "bf16", True)
+        plain.add_synth(0, n, spec)
+        batches = [oracle_mod.synth_rows(16 * j, 3, dim, qspec) for j in range(5)]
+        want = [plain.search(q, 10, 40) for q in batches]
+        qd = [torch.from_numpy(q).cuda() for q in batches]
+        got = []
+        for j, q in enumerate(qd):                      # pipelined: results read only after wait_results()
+            idx, dd = sh.search(q, 10, 40, wait=False)
+            sh.wait_results()
+            got.append((idx.cpu().numpy().copy(), dd.cpu().numpy().copy()))
+        for (gi, gd), (wi, wd) in zip(got, want):
+            assert np.array_equal(gi, wi) and np.array_equal(gd, wd)
+        # back to back without reading in between, then one device sync: the last two answers are still intact
+        outs = [sh.search(q, 10, 40, wait=False) for q in qd]
+        torch.cuda.synchronize()
+        for j in (3, 4):
+            assert np.array_equal(outs[j][0].cpu().numpy(), want[j][0]) and np.array_equal(outs[j][1].cpu().numpy(), want[j][1])
+        idx, dd = sh.search(qd[0], 10, 40)               # wait=True: ordered on the current stream
+        assert np.array_equal(idx.cpu().numpy(), want[0][0]) and np.array_equal(dd.cpu().numpy(), want[0][1])
+        sh.close()
+        plain.close()
+    finally:
+        dist.destroy_process_group()

@@ -90,6 +90,15 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
                 raise ImportError(
                     f"{HIP_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                     "(hipcc --offload-arch=gfx950).  vectordb_amd has no CPU fallback.")
+            # PyTorch-ROCm bundles its own HIP runtime.  If THIS library were loaded first it would bind to
+            # the system runtime, the process would hold two, and whichever initialises second may find no
+            # device (seen on MI355X: torch initialised first, then vdb_create -> hipErrorNoDevice).
+            # Importing torch first makes the engine bind to the runtime torch uses: one runtime per process,
+            # which is also what lets torch tensors' device pointers be passed to the *_dev entry points.
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
             _default_lib = _declare(C.CDLL(HIP_LIB_PATH))
         return _default_lib
     return _declare(C.CDLL(path))

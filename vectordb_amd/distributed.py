@@ -5,8 +5,11 @@ One process per GPU (`torch.distributed`, backend "nccl" = RCCL over xGMI on
 ROCm; "gloo" on CPU for tests).  Rank r owns the contiguous row range
 [r*ceil(N/G), min(N,(r+1)*ceil(N/G))) and reports *global* row indices.  A
 query runs as: local scan (+ local fp32 rerank) -> ONE all-gather of the packed
-per-rank top-k (k*(4+8) bytes per query per rank) -> on-device merge.  PyTorch
-is used for device buffers, streams and the collective only.
+per-rank top-k (k*(4+8) bytes per query per rank) -> on-device merge.  The
+exchange runs on a side stream with two buffer sets, so a throughput-oriented
+caller (wait=False) overlaps it with the next batch's scan: at 8 GPUs the
+latency-bound all-gather is otherwise ~15 % of a 0.3 ms shard scan.  PyTorch is
+used for device buffers, streams and the collective only.
 """
 from __future__ import annotations
 
@@ -26,8 +29,11 @@ def shard_range(n_total: int, rank: int, world: int) -> Tuple[int, int]:
 
 class ShardedIndex:
     def __init__(self, dim: int, dtype: str = "bf16", keep_f32_for_rerank: bool = True, *,
-                 device: Optional[torch.device] = None, group=None, lib=None):
+                 device: Optional[torch.device] = None, group=None, lib=None, force_collective: bool = False):
         self.group = group
+        self.force_collective = bool(force_collective) and dist.is_initialized()   # world 1: still run the exchange (tests)
+        self._side = None
+        self._last_done = None
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.device = torch.device(device) if device is not None else torch.device("cpu")
@@ -54,40 +60,85 @@ class ShardedIndex:
         self.n_total = n_total
 
     # -- search ----------------------------------------------------------------
+    _RING = 2   # buffer sets per (b, k): lets the exchange of one batch overlap the scan of the next
+
     def _buffers(self, b: int, k: int):
         key = (b, k)
         if key not in self._bufs:
             # packed per-rank result: [ idx int64 b*k | dist fp32 b*k (padded to 8 B) ]
             words = b * k + (b * k + 1) // 2
-            local = torch.empty(words, dtype=torch.int64, device=self.device)
-            gathered = torch.empty(self.world * words, dtype=torch.int64, device=self.device)
-            out_idx = torch.empty((b, k), dtype=torch.int64, device=self.device)
-            out_dist = torch.empty((b, k), dtype=torch.float32, device=self.device)
-            self._bufs[key] = (words, local, gathered, out_idx, out_dist)
+            sets = []
+            for _ in range(self._RING):
+                local = torch.empty(words, dtype=torch.int64, device=self.device)
+                gathered = torch.empty(self.world * words, dtype=torch.int64, device=self.device)
+                out_idx = torch.empty((b, k), dtype=torch.int64, device=self.device)
+                out_dist = torch.empty((b, k), dtype=torch.float32, device=self.device)
+                cuda = self.device.type == "cuda"
+                sets.append({"local": local, "gathered": gathered, "out_idx": out_idx, "out_dist": out_dist,
+                             "ready": torch.cuda.Event() if cuda else None, "done": torch.cuda.Event() if cuda else None,
+                             "used": False})
+            self._bufs[key] = {"words": words, "sets": sets, "next": 0}
         return self._bufs[key]
 
     def _stream(self) -> int:
         return torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else 0
 
-    def search(self, queries: torch.Tensor, k: int, rerank_kprime: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
+    def search(self, queries: torch.Tensor, k: int, rerank_kprime: int = 0, wait: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
         """queries: [b, dim] fp32 tensor on self.device, identical on every rank.
         Returns (idx [b,k] int64 global rows, dist [b,k] fp32) on every rank.  The
-        returned tensors are reused by the next call with the same (b, k)."""
+        returned tensors are reused by the second-next call with the same (b, k).
+
+        On a GPU with more than one rank the exchange (all-gather + merge) runs on a
+        side stream.  wait=True (default) makes the current stream wait for it, so the
+        results are ordered like any other work on that stream.  wait=False returns at
+        once — the next batch's scan then overlaps this batch's exchange; call
+        `wait_results()` (or synchronise the device) before using the tensors."""
         assert queries.dtype == torch.float32 and queries.is_contiguous() and queries.shape[1] == self.dim
         b = queries.shape[0]
-        words, local, gathered, out_idx, out_dist = self._buffers(b, k)
+        ring = self._buffers(b, k)
+        words = ring["words"]
+        cur = ring["sets"][ring["next"]]
+        ring["next"] = (ring["next"] + 1) % self._RING
+        cuda = self.device.type == "cuda"
+        collective = self.world > 1 or self.force_collective
+        if cuda and collective and cur["used"]:
+            torch.cuda.current_stream(self.device).wait_event(cur["done"])   # this set's previous exchange has finished
         st = self._stream()
+        local = cur["local"]
         idx_ptr = local.data_ptr()
         dist_ptr = idx_ptr + 8 * b * k
         self.local.search_device(queries.data_ptr(), b, k, rerank_kprime, idx_ptr, dist_ptr, st)
-        if self.world == 1:
+        if not collective:
             # the local result is already final (same (distance, index) ordering rule as the merge)
             return local[: b * k].view(b, k), local[b * k:].view(torch.float32)[: b * k].view(b, k)
-        dist.all_gather_into_tensor(gathered, local, group=self.group)
+        gathered, out_idx, out_dist = cur["gathered"], cur["out_idx"], cur["out_dist"]
         g_idx = gathered.data_ptr()
-        self.local.merge_topk_device(g_idx + 8 * b * k, g_idx, self.world, b, k, out_idx.data_ptr(),
-                                     out_dist.data_ptr(), st, dist_shard_stride=2 * words, idx_shard_stride=words)
+        if not cuda:
+            dist.all_gather_into_tensor(gathered, local, group=self.group)
+            self.local.merge_topk_device(g_idx + 8 * b * k, g_idx, self.world, b, k, out_idx.data_ptr(),
+                                         out_dist.data_ptr(), 0, dist_shard_stride=2 * words, idx_shard_stride=words)
+            return out_idx, out_dist
+        if self._side is None:
+            self._side = torch.cuda.Stream(self.device)
+        main = torch.cuda.current_stream(self.device)
+        cur["ready"].record(main)
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(cur["ready"])
+            dist.all_gather_into_tensor(gathered, local, group=self.group)
+            self.local.merge_topk_device(g_idx + 8 * b * k, g_idx, self.world, b, k, out_idx.data_ptr(),
+                                         out_dist.data_ptr(), self._side.cuda_stream,
+                                         dist_shard_stride=2 * words, idx_shard_stride=words)
+            cur["done"].record(self._side)
+        cur["used"] = True
+        self._last_done = cur["done"]
+        if wait:
+            main.wait_event(cur["done"])
         return out_idx, out_dist
+
+    def wait_results(self) -> None:
+        """Order the current stream after the last exchange started with wait=False."""
+        if self._last_done is not None:
+            torch.cuda.current_stream(self.device).wait_event(self._last_done)
 
     def close(self) -> None:
         self.local.close()
