@@ -8,9 +8,10 @@ queries against the 10M x 768 synthetic corpus, answered by the engine three way
 
 and checked against a streamed CPU brute force over the same corpus regenerated chunk by
 chunk on the host (the oracle's generator is bit-identical to the device's; fp64 scores).
-The oracle is used here as the checker only.  Prints one JSON document.
+The oracle is used here as the checker only (which is why this script lives under tests/;
+pytest does not collect it).  Prints one JSON document.
 
-  python3 benchmarks/verify_10m.py [--rows 10000000] [--queries 64]
+  python3 tests/verify_10m.py [--rows 10000000] [--queries 64]
 """
 import argparse
 import json
