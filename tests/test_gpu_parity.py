@@ -459,3 +459,25 @@ def test_sharded_exchange_on_side_stream(hip_lib, oracle_mod, corpus20k):
         plain.close()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("b,k,kp", [(1024, 10, 40), (256, 30, 64), (300, 64, 0), (64, 1, 4), (40, 30, 120)])
+def test_mfma_shapes_at_the_limits(hip_lib, oracle_mod, corpus20k, b, k, kp):
+    """The batched path at its limits: the full 4-query-tile batch of the bench, k' = 64 (its
+    maximum), k = 64 without rerank, k = 1, and k' = 120 (> 64: the batch must take the GEMV
+    path and still be right)."""
+    n, dim, spec, rows, _ = corpus20k
+    qspec = SynthSpec(seed=777, kind=2, noise=0.5, base_kind=1, base_seed=1234, base_n=n, base_n_clusters=141, base_noise=0.3)
+    queries = oracle_mod.synth_rows(0, b, dim, qspec)
+    ix = FlatIndex(dim, "bf16", True)
+    ix.add_synth(0, n, spec)
+    idx, dist = ix.search(queries, k, kp)
+    assert ix.get_stat("mfma_last_overflow") == 0
+    r_idx, r_dist, r_sc = oracle_mod.exact_topk(rows, queries, k)
+    if kp:
+        swaps = check_topk(idx, dist, r_idx, r_dist, r_sc, rows, _qn(oracle_mod, queries), what=f"mfma b={b} k={k} k'={kp}")
+        assert recall_at_k(idx, r_idx) >= 1.0 - swaps / idx.size - 1e-12
+    else:   # bf16 x bf16 scores only: loose
+        assert recall_at_k(idx, r_idx) >= 0.9 and np.allclose(dist, r_dist, atol=3e-3)
+        assert np.all(np.diff(dist, axis=1) >= 0)
+    ix.close()
