@@ -41,7 +41,7 @@ def synth_queries(ix, b, qspec):
 
 def main():
     out = {}
-    which = set(sys.argv[1:]) or {"c1", "c2", "c4", "c5"}
+    which = set(sys.argv[1:]) or {"c1", "c2", "c3host", "c4", "c5"}
     dim = 768
     if "c1" in which:   # real-catalog size through the Chroma-shaped API (embeddings synthetic: SURVEY 8c)
         n = 14777
@@ -79,6 +79,23 @@ def main():
         out["C2_1Mx768_f32_b1"] = {"qps": 1 / step, "scan_ms": scan_ms, "finish_ms": fin_ms,
                                    "scan_GBps": n * dim * 4 / scan_ms / 1e6, "frac_hbm_peak": n * dim * 4 / scan_ms / 1e6 / 8000,
                                    "roofline_qps": 2604}
+        ix.close()
+    if "c3host" in which:   # the bench workload through the HOST-pointer entry point (PCIe in the loop)
+        n = 10_000_000
+        spec = SynthSpec(seed=1234, kind=1, n_clusters=3162, noise=0.3)
+        qspec = SynthSpec(seed=1235, kind=2, noise=0.5, base_kind=1, base_seed=1234, base_n=n, base_n_clusters=3162, base_noise=0.3)
+        ix = FlatIndex(dim, "bf16", True)
+        ix.add_synth(0, n, spec)
+        res = {}
+        for b, iters in ((1, 100), (1024, 8)):
+            q = synth_queries(ix, b, qspec).cpu().numpy()
+            ix.search(q, 10, 40)
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                ix.search(q, 10, 40)          # vdb_search: H2D queries, search, D2H results, synchronous
+            dt = (time.perf_counter() - t0) / iters
+            res[f"b{b}"] = {"qps_host_pointers": b / dt, "ms_per_call": dt * 1e3}
+        out["C3_10Mx768_bf16_host_pointer_calls"] = res
         ix.close()
     if "c4" in which:   # one shard of the 100M x 768 bf16 corpus over 8 GPUs: 12.5M rows
         n = 12_500_000
