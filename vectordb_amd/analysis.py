@@ -242,7 +242,9 @@ def generate_best_usda_matches(vector_db, mapping_df: pd.DataFrame, transaction_
     by_id = {i: np.asarray(e, dtype=np.float32) for i, e in zip(got["ids"], got["embeddings"] if got["ids"] else [])}
     emb: List[Optional[np.ndarray]] = [by_id.get(w) if on_id_hit == "use" else None for w in want]
     pid: List[Any] = [w if w in by_id else None for w in want]
-    miss = [j for j, w in enumerate(want) if w not in by_id]
+    # a description that is not text (NaN) cannot be embedded: the reference's fallback query raises on it, prints,
+    # and the row is skipped (generate_best_usda_matches.py:201-203) — three such rows in its own data
+    miss = [j for j, w in enumerate(want) if w not in by_id and isinstance(descs[j], str)]
     if miss and vector_db.collection.count():
         q = _embed_many(vector_db, [descs[j] for j in miss])
         res = vector_db.collection.query(query_embeddings=q, n_results=1, include=["embeddings"])

@@ -23,6 +23,11 @@ _NS = {"m": "http://schemas.openxmlformats.org/spreadsheetml/2006/main",
        "r": "http://schemas.openxmlformats.org/officeDocument/2006/relationships",
        "p": "http://schemas.openxmlformats.org/package/2006/relationships"}
 _COL_RE = re.compile(r"([A-Z]+)")
+# pandas.read_excel's default NA strings (keep_default_na=True): such a TEXT cell becomes NaN.  The reference's
+# transaction report holds two descriptions that are the literal text "None"; pandas drops them as missing, which
+# is why its store has 14 777 products, not 14 778.
+_NA_STRINGS = frozenset(["", "#N/A", "#N/A N/A", "#NA", "-1.#IND", "-1.#QNAN", "-NaN", "-nan", "1.#IND", "1.#QNAN", "<NA>",
+                         "N/A", "NA", "NULL", "NaN", "None", "n/a", "nan", "null"])
 
 
 def _col_index(ref: str) -> int:
@@ -104,7 +109,7 @@ def _read_xlsx_stdlib(path, sheet_name=0) -> pd.DataFrame:
                             val = None
                         else:
                             val = _number(v.text)
-                    if val is not None and val != "":
+                    if val is not None and not (isinstance(val, str) and val in _NA_STRINGS):
                         cells[ci] = val
                 rows.append((r_idx, cells))
                 row.clear()

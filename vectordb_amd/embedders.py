@@ -79,6 +79,13 @@ class MPNetEmbedder:
         return out
 
 
+def SentenceTransformerEmbeddingFunction(model_name: str = "all-mpnet-base-v2", **_ignored):
+    """Same name and call shape as chromadb.utils.embedding_functions' class, so that
+    `from vectordb_amd import embedders as embedding_functions` leaves the reference's
+    `src/vectordb.py:17` unchanged.  Resolves offline only (see resolve_embedder)."""
+    return resolve_embedder(model_name)
+
+
 def resolve_embedder(model_name: str, embed_fn: Callable = None):
     """embed_fn wins; a local directory -> MPNetEmbedder; 'hash'/'hash:<dim>' -> HashEmbedder."""
     if embed_fn is not None:
