@@ -90,3 +90,12 @@ def test_best_match_rows_and_ground_truth_columns_equal_the_recorded_output(ref_
     # and the recorded output obeys the same rule
     rk = recorded[recorded["known_usda_code"].notna()]
     assert ((rk["is_correct_match"].astype(str) == "True") == (rk["known_usda_code"] == rk["best_matching_usda_code"])).all()
+
+
+def test_summary_counts_of_the_recorded_output(recorded):
+    """The counts generate_best_usda_matches.py prints at its end (:291-325), computed by this build's
+    summarize_best_matches on the reference's recorded output."""
+    from vectordb_amd import analysis
+    s = analysis.summarize_best_matches(recorded)
+    assert s["total_products"] == 15235 and s["known"] == 73 and s["unknown"] == 15162
+    assert s["correct"] == 31 and s["incorrect"] == 42 and s["accuracy"] == pytest.approx(31 / 73)
