@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--force-collective", action="store_true",
                     help="diagnostic, 1 GPU: run the all-gather + merge exchange with a single-rank RCCL group")
     ap.add_argument("--sync-exchange", action="store_true", help="diagnostic: wait for each batch's exchange (no overlap)")
+    ap.add_argument("--mfma-min-b", type=int, default=0, help="diagnostic: smallest batch sent to the MFMA path")
     ap.add_argument("--clusters", type=int, default=0, help="synthetic clusters (default sqrt(rows))")
     ap.add_argument("--ablate", type=int, default=0, help="diagnostic: MFMA kernel ablation bits (results invalid)")
     args = ap.parse_args()
@@ -130,6 +131,8 @@ def main():
         sh.local.set_option("mfma_variant", args.mfma_variant)
     if args.ablate:
         sh.local.set_option("mfma_ablate", args.ablate)
+    if args.mfma_min_b:
+        sh.local.set_option("batch_mfma_min_b", args.mfma_min_b)
     if args.nt >= 0:
         sh.local.set_option("scan_nt_loads", args.nt)
     # a pool of distinct query batches, resident in HBM
@@ -187,7 +190,7 @@ def main():
 
     if rank == 0:
         esz = 2 if args.dtype == "bf16" else 4
-        mfma = b >= 16 and args.dtype == "bf16"
+        mfma = b >= (args.mfma_min_b or 3) and args.dtype == "bf16"   # the engine's cost model agrees at 10M rows (vdb_api.hip)
         scan_ms = tstats["scan_ms_sum"] / max(tstats["n"], 1)
         if mfma:
             alg = 2.0 * b * n_local * dim

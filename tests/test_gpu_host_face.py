@@ -52,6 +52,7 @@ def twin_dbs(tmp_path_factory, hip_lib, oracle_lib):
 def test_classification_harness_hip_equals_oracle(twin_dbs):
     hip, ora, _, mapping_df, tx = twin_dbs
     thr = 0.30
+    hip.collection._index.set_option("mfma_cost_model", 0)   # 20 queries x 4 500 rows sit at the cost model's crossover: force MFMA
     out_h = analysis.evaluate_usda_classification(hip, mapping_df, tx, similarity_threshold=thr, max_results=10)
     out_o = analysis.evaluate_usda_classification(ora, mapping_df, tx, similarity_threshold=thr, max_results=10)
     assert hip.collection._index.get_stat("mfma_last_hits") > 0          # 20 queries, k'=40, 4 500 bf16 rows: the MFMA path served it

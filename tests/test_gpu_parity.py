@@ -256,6 +256,7 @@ def test_mfma_batch_parity(hip_lib, oracle_mod, corpus20k, b):
     qspec = SynthSpec(seed=321, kind=2, noise=0.5, base_kind=1, base_seed=1234, base_n=n, base_n_clusters=141, base_noise=0.3)
     queries = oracle_mod.synth_rows(0, b, dim, qspec)
     ix = FlatIndex(dim, "bf16", True)
+    ix.set_option("mfma_cost_model", 0)   # the MFMA path is what this test is about
     ix.add_synth(0, n, spec)
     idx, dist = ix.search(queries, 10, 40)
     r_idx, r_dist, r_sc = oracle_mod.exact_topk(rows, queries, 10)
@@ -282,6 +283,7 @@ def test_mfma_multi_tile_per_block_and_selfjoin(hip_lib, oracle_mod):
     rows = oracle_mod.normalize_rows(oracle_mod.synth_rows(0, n, dim, spec))
     queries = oracle_mod.synth_rows(0, b, dim, qspec)
     ix = FlatIndex(dim, "bf16", True)
+    ix.set_option("mfma_cost_model", 0)   # the MFMA path is what this test is about
     ix.add_synth(0, n, spec)
     idx, dist = ix.search(queries, 10, 40)
     r_idx, r_dist, r_sc = oracle_mod.exact_topk(rows, queries, 10)
@@ -305,6 +307,7 @@ def test_mfma_kernel_variants_agree(hip_lib, oracle_mod, corpus20k, variant):
     qspec = SynthSpec(seed=4242, kind=2, noise=0.5, base_kind=1, base_seed=1234, base_n=n, base_n_clusters=141, base_noise=0.3)
     queries = oracle_mod.synth_rows(0, 256, dim, qspec)
     ix = FlatIndex(dim, "bf16", True)
+    ix.set_option("mfma_cost_model", 0)   # the MFMA path is what this test is about
     ix.add_synth(0, n, spec)
     i5, d5 = ix.search(queries, 10, 40)
     ix.set_option("mfma_variant", variant)
@@ -322,6 +325,7 @@ def test_mfma_wide_multi_tile_and_selfjoin(hip_lib, oracle_mod):
     rows = oracle_mod.normalize_rows(oracle_mod.synth_rows(0, n, dim, spec))
     queries = oracle_mod.synth_rows(0, b, dim, qspec)
     ix = FlatIndex(dim, "bf16", True)
+    ix.set_option("mfma_cost_model", 0)   # the MFMA path is what this test is about
     ix.add_synth(0, n, spec)
     idx, dist = ix.search(queries, 10, 40)
     assert ix.get_stat("mfma_last_overflow") == 0
@@ -350,6 +354,7 @@ def test_mfma_adversarial_order(hip_lib, oracle_mod):
     rows[-3:] = rows[-4]          # duplicates at the very top
     rows_n = oracle_mod.normalize_rows(rows)
     ix = FlatIndex(dim, "bf16", True)
+    ix.set_option("mfma_cost_model", 0)   # the MFMA path is what this test is about
     ix.add(rows)
     idx, dist = ix.search(q, 10, 48)
     r_idx, r_dist, r_sc = oracle_mod.exact_topk(rows_n, q, 10)
@@ -364,6 +369,7 @@ def test_mfma_overflow_fallback(hip_lib, oracle_mod, corpus20k):
     qspec = SynthSpec(seed=555, kind=2, noise=0.5, base_kind=1, base_seed=1234, base_n=n, base_n_clusters=141, base_noise=0.3)
     queries = oracle_mod.synth_rows(0, 40, dim, qspec)
     ix = FlatIndex(dim, "bf16", True)
+    ix.set_option("mfma_cost_model", 0)   # the MFMA path is what this test is about
     ix.add_synth(0, n, spec)
     base_idx, base_dist = ix.search(queries, 10, 40)
     r_idx, r_dist, r_sc = oracle_mod.exact_topk(rows, queries, 10)
@@ -470,6 +476,7 @@ def test_mfma_shapes_at_the_limits(hip_lib, oracle_mod, corpus20k, b, k, kp):
     qspec = SynthSpec(seed=777, kind=2, noise=0.5, base_kind=1, base_seed=1234, base_n=n, base_n_clusters=141, base_noise=0.3)
     queries = oracle_mod.synth_rows(0, b, dim, qspec)
     ix = FlatIndex(dim, "bf16", True)
+    ix.set_option("mfma_cost_model", 0)   # the MFMA path is what this test is about
     ix.add_synth(0, n, spec)
     idx, dist = ix.search(queries, k, kp)
     assert ix.get_stat("mfma_last_overflow") == 0

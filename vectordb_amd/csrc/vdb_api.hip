@@ -47,7 +47,8 @@ struct vdb {
   // options
   int scan_blocks_per_cu = 4;
   int scan_nt_loads = 1;
-  int batch_mfma_min_b = 16;
+  int batch_mfma_min_b = 3;      // smallest batch the MFMA path may serve (the cost model decides above it)
+  int mfma_cost_model = 1;       // 0: every supported batch >= batch_mfma_min_b takes the MFMA path (tests)
   int mfma_ablate = 0;   // diagnostic: skip parts of the MFMA kernel (wrong results, timing only)
   // workspaces (grown on demand)
   DevBuf w_q, w_part_s, w_part_i, w_part2_s, w_part2_i, w_stage, w_out_i, w_out_d, w_idx, w_mfma;
@@ -405,6 +406,21 @@ int mfma_search(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
   return VDB_OK;
 }
 
+// Which path serves a bf16 768-d batch faster?  Coefficients measured on MI355X (round 1, 10M and 1M rows):
+// a GEMV pass costs a launch (~12 us) plus the corpus at ~6.7 TB/s, times 1.0 / 1.18 / 1.64 for 1 / 2 / 4
+// queries per pass (b = 3 runs as 2 + 1); the MFMA path costs ~100 us of launches (dense sample, selects,
+// append passes) plus 0.29 ns per row and 128-query tile, or 0.36 (+0.05) ns per row and 256-query tile.
+// Measured crossover at 10M rows: b = 2 GEMV 2.72 ms vs MFMA 2.96; b = 3 5.16 vs 3.01; b = 8 7.58 vs 3.13.
+bool mfma_is_faster(int b, int n_rows) {
+  const double pass = 12e-6 + (double)n_rows * kMfRowBytes / 6.7e12;
+  const int r = b & 3;
+  const double gemv = pass * (1.64 * (b >> 2) + (r == 3 ? 2.18 : r == 2 ? 1.18 : r == 1 ? 1.0 : 0.0));
+  const int pad_wide = ((b + kM5BN - 1) / kM5BN) * kM5BN, pad_narrow = ((b + kMfBN - 1) / kMfBN) * kMfBN;
+  const bool wide = 2 * pad_wide <= 3 * pad_narrow;
+  const double mfma = 100e-6 + (double)n_rows * (wide ? 0.36e-9 * (pad_wide / kM5BN) + 0.05e-9 : 0.29e-9 * (pad_narrow / kMfBN));
+  return mfma < gemv;
+}
+
 // Core search over device-resident, already *normalised* queries qn [b][ld].
 // self_row0 >= 0: query q excludes row self_row0+q.
 int search_core(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_row0, int64_t* out_idx,
@@ -431,8 +447,9 @@ int search_core(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
     return VDB_OK;
   }
 
-  // MFMA batched path (bf16 store, fast dim, enough queries)
-  if (bf16 && h->dim == 768 && h->ld == 768 && b >= h->batch_mfma_min_b && mfma_path_supported(kk) && n_rows >= 4096) {
+  // MFMA batched path (bf16 store, fast dim, enough queries that it beats ceil(b/4) GEMV passes)
+  if (bf16 && h->dim == 768 && h->ld == 768 && b >= h->batch_mfma_min_b && mfma_path_supported(kk) && n_rows >= 4096 &&
+      (!h->mfma_cost_model || mfma_is_faster(b, n_rows))) {
     int rc = mfma_search(h, qn, b, k, kp, self_row0, out_idx, out_dist, st);
     return rc;
   }
@@ -857,6 +874,7 @@ int vdb_set_option(vdb_t* h, const char* name, int64_t value) {
     if (value < 256 || value > (1 << 22)) return fail(h, VDB_ERR_ARG, "mfma_append_cap must be in [256, 4194304]");
     h->mfma_append_cap = (int)value; return VDB_OK;
   }
+  if (!strcmp(name, "mfma_cost_model")) { h->mfma_cost_model = value != 0; return VDB_OK; }
   if (!strcmp(name, "batch_mfma_min_b")) { if (value < 1) return fail(h, VDB_ERR_ARG, "batch_mfma_min_b must be >= 1"); h->batch_mfma_min_b = (int)std::min<int64_t>(value, 1 << 30); return VDB_OK; }
   return fail(h, VDB_ERR_ARG, std::string("set_option: unknown option ") + name);
 }
