@@ -48,6 +48,7 @@ struct vdb {
   int scan_blocks_per_cu = 4;
   int scan_nt_loads = 1;
   int batch_mfma_min_b = 3;      // smallest batch the MFMA path may serve (the cost model decides above it)
+  bool mfma_attr_set = false;    // dynamic-LDS limits of the MFMA kernels raised on this handle's device
   int mfma_cost_model = 1;       // 0: every supported batch >= batch_mfma_min_b takes the MFMA path (tests)
   int mfma_ablate = 0;   // diagnostic: skip parts of the MFMA kernel (wrong results, timing only)
   // workspaces (grown on demand)
@@ -298,8 +299,7 @@ int mfma_search(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
   const size_t part_elems = (size_t)b * fb.n_splits * kk;
   if ((rc = ensure(h, h->w_part_s, part_elems * 4))) return rc;
   if ((rc = ensure(h, h->w_part_i, part_elems * 4))) return rc;
-  static bool attr_set = false;
-  if (!attr_set) {
+  if (!h->mfma_attr_set) {   // per handle = per device: the limit is a property of the function ON a device
     HIP_TRY(h, hipFuncSetAttribute((const void*)scan_mfma_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_smem_bytes()));
     HIP_TRY(h, hipFuncSetAttribute((const void*)scan_mfma_pass_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kMfNumStages * kMfStage));
     HIP_TRY(h, hipFuncSetAttribute((const void*)scan_mfma_pass_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kMfNumStages * kMfStage));
@@ -310,7 +310,7 @@ int mfma_search(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
     HIP_TRY(h, hipFuncSetAttribute((const void*)scan_mfma_wide_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m5_smem_bytes()));
     HIP_TRY(h, hipFuncSetAttribute((const void*)scan_mfma_wide_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m5_smem_bytes()));
     HIP_TRY(h, hipFuncSetAttribute((const void*)scan_mfma_wide_kernel<1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m5_smem_bytes()));
-    attr_set = true;
+    h->mfma_attr_set = true;
   }
   const unsigned char* qb16 = (const unsigned char*)h->w_mfma.p;
   float* cand_s = (float*)h->w_cand_s.p;
