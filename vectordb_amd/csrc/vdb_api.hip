@@ -1,6 +1,7 @@
 // vdb_api.hip — C ABI (include/vdb.h) of the MI355X-native cosine top-k engine.
-// Host-side orchestration only: all arithmetic is in the HIP kernels of
-// scan_gemv.h / scan_mfma.h / select.h.  gfx950 only; no CPU fallback.
+// Host-side orchestration only: all arithmetic is in the HIP kernels of scan_gemv.h (batch-1 / small
+// batches, HBM-bound), scan_mfma{,3,4,5}.h (batched bf16 path on MFMA) and select.h (merges, fp32 rerank,
+// shard merge).  gfx950 only; no CPU fallback.
 #include <hip/hip_runtime.h>
 #include <sys/stat.h>
 #include <algorithm>
@@ -56,7 +57,7 @@ struct vdb {
   DevBuf w_cand_s, w_cand_i, w_cand_cnt, w_thr, w_dense, w_list_s, w_list_i;   // append-path state
   int mfma_append_cap = 16384;   // candidate buffer entries per query
   int mfma_variant = 5;          // 3 = barrier ring (scan_mfma3.h), 4 = warp-specialised (scan_mfma4.h),
-                                 // 5 = 256x256 tile (scan_mfma5.h) when that pads the batch no further, else 4
+                                 // 5 = 256x256 tile (scan_mfma5.h) unless it pads the batch > 1.5x further, then 4
   int mfma_last_b = 0;           // batch size of the last MFMA search (locates its overflow flag)
   int mfma_force_fallback = 0;   // test hook: route through the exact list kernel
   std::string err;
