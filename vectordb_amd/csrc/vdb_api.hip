@@ -46,7 +46,7 @@ struct vdb {
   double last_bytes = 0.0;
   int n_cu = 256;
   // options
-  int scan_blocks_per_cu = 4;
+  int scan_blocks_per_cu = 2;    // 2 x 256 threads per CU: 96 KiB in flight per CU; 4 measured 3-4 % slower at every shard size (bf16)
   int scan_nt_loads = 1;
   int batch_mfma_min_b = 3;      // smallest batch the MFMA path may serve (the cost model decides above it)
   bool mfma_attr_set = false;    // dynamic-LDS limits of the MFMA kernels raised on this handle's device
