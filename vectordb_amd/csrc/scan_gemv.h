@@ -17,6 +17,10 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kScanThreads = 256;
+#ifndef VDB_SCAN_LOADS_IN_FLIGHT
+#define VDB_SCAN_LOADS_IN_FLIGHT 12
+#endif
+constexpr int kScanLoadsInFlight = VDB_SCAN_LOADS_IN_FLIGHT;   // 16-byte loads a lane keeps in flight (1 KiB per wave each)
 constexpr int kScanWaves = kScanThreads / 64;
 
 __host__ __device__ constexpr int cgcd(int a, int b) { return b == 0 ? a : cgcd(b, a % b); }
@@ -110,7 +114,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_topk_kernel(const void* __r
   constexpr int G = cgcd(CPR, 64);
   constexpr int L = CPR / G;                      // wave-loads per group
   constexpr int R = 64 / G;                       // rows per group
-  constexpr int U = (L >= 12) ? 1 : (12 / L);     // groups per tile
+  constexpr int U = (L >= kScanLoadsInFlight) ? 1 : (kScanLoadsInFlight / L);     // groups per tile
   constexpr int RPT = U * R;                      // rows per tile
   static_assert(DIM % EPC == 0, "row must be a whole number of 16-byte chunks");
 
