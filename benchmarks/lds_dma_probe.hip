@@ -10,6 +10,10 @@
 // and K-step).  SEG = 64: a piece covers 16 rows x 64 B and the other half of each line is
 // fetched by the NEXT stage (what a K=32 stage would do).  Source: a [rows][1536 B] matrix; all
 // blocks of an XCD walk the same rows (L2-shared, as the kernel's query/corpus tiles are).
+// PRIVATE = 1: every block streams its own L2-resident 96 KiB instead — no line is requested by
+// two CUs.  It reads at the same ~57-59 GB/s per CU, so the rate is the L2 -> L1 fill path of a
+// CU, not contention between CUs for shared lines.  (A footprint that fits the 32 KiB L1 reads
+// at ~150 GB/s per CU; nothing on the kernel's staging path is that small.)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -21,7 +25,7 @@ __device__ __forceinline__ void glds16(const unsigned char* g, unsigned char* l)
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-template <int SEG, int KEEP, int SLOTS>
+template <int SEG, int KEEP, int SLOTS, int PRIVATE = 0>
 __global__ __launch_bounds__(512) void probe(const unsigned char* __restrict__ src, long long n_rows, int n_stages, int rows_per_block_stage) {
   extern __shared__ __align__(16) unsigned char smem[];
   constexpr int RING = KEEP + 1;
@@ -37,9 +41,18 @@ __global__ __launch_bounds__(512) void probe(const unsigned char* __restrict__ s
     // SEG=128: K-step = stage % 12, row window advances every 12 stages.  SEG=64: 24 half steps.
     constexpr int KSTEPS = 1536 / SEG;
     const int ks = stage % KSTEPS;
+    unsigned char* st = smem + ((stage % RING) * 8 + w) * SLOTS * 1024;
+    if (PRIVATE) {
+      // every block streams its OWN 96 KiB region round and round, as dense 128-byte lines: L2-resident (3 MiB per
+      // XCD), three times the 32 KiB L1, and no line is ever requested by two CUs
+      const unsigned char* reg = src + (size_t)blockIdx.x * (96 << 10);
+      const size_t off = ((size_t)stage * 8 * SLOTS * 1024) % (96 << 10);
+#pragma unroll
+      for (int i = 0; i < SLOTS; ++i) glds16(reg + (off + (size_t)(w * SLOTS + i) * 1024) % (96 << 10) + lane * 16, st + i * 1024);
+      return;
+    }
     const long long win = ((long long)(stage / KSTEPS) * rows_per_block_stage) % (xcd_rows - rows_per_block_stage);
     const unsigned char* p = base + (size_t)win * 1536 + (size_t)ks * SEG + (size_t)w * SLOTS * ROWS_PER_PIECE * 1536;
-    unsigned char* st = smem + ((stage % RING) * 8 + w) * SLOTS * 1024;
 #pragma unroll
     for (int i = 0; i < SLOTS; ++i) glds16(p + (size_t)i * ROWS_PER_PIECE * 1536 + lane_off, st + i * 1024);
   };
@@ -60,17 +73,17 @@ __global__ __launch_bounds__(512) void probe(const unsigned char* __restrict__ s
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int SEG, int KEEP, int SLOTS>
+template <int SEG, int KEEP, int SLOTS, int PRIVATE = 0>
 void run(const unsigned char* d, long long n_rows, const char* what) {
   const int n_stages = 6000;
   const int rows_per_block_stage = 8 * SLOTS * (1024 / SEG);   // rows one block covers per stage
   const size_t smem = (size_t)(KEEP + 1) * 8 * SLOTS * 1024;
-  CHECK(hipFuncSetAttribute((const void*)probe<SEG, KEEP, SLOTS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  CHECK(hipFuncSetAttribute((const void*)probe<SEG, KEEP, SLOTS, PRIVATE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
   for (int rep = 0; rep < 2; ++rep) {
     CHECK(hipEventRecord(e0));
-    hipLaunchKernelGGL((probe<SEG, KEEP, SLOTS>), dim3(256), dim3(512), smem, 0, d, n_rows, n_stages, rows_per_block_stage);
+    hipLaunchKernelGGL((probe<SEG, KEEP, SLOTS, PRIVATE>), dim3(256), dim3(512), smem, 0, d, n_rows, n_stages, rows_per_block_stage);
     CHECK(hipEventRecord(e1));
     CHECK(hipEventSynchronize(e1));
   }
@@ -90,6 +103,8 @@ int main() {
   run<128, 1, 4>(d, n_rows, "32 KiB stages, 1 kept");
   run<128, 2, 4>(d, n_rows, "32 KiB stages, 2 kept");
   run<128, 3, 4>(d, n_rows, "32 KiB stages, 3 kept");
+  run<128, 1, 8, 1>(d, n_rows, "64 KiB stages, 1 kept, PRIVATE rows");
+  run<128, 2, 4, 1>(d, n_rows, "32 KiB stages, 2 kept, PRIVATE rows");
   run<64, 0, 4>(d, n_rows, "32 KiB half-line burst, drained");
   run<64, 1, 4>(d, n_rows, "32 KiB half-line stages, 1 kept");
   run<64, 2, 4>(d, n_rows, "32 KiB half-line stages, 2 kept");
