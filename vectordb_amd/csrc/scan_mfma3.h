@@ -263,4 +263,28 @@ __global__ __launch_bounds__(1024) void select_kth_dense_kernel(const float* __r
   if (w == 0 && lane == 0) thr_out[q] = tk.thr_s;
 }
 
+// Cheap valid threshold from the dense sample, one wave per query: lane l takes the maximum of the scores
+// l, l+64, l+128, ...; the kk-th largest of the 64 lane maxima (kk <= 64) is the score of an actual sampled
+// row with at least kk sampled rows at or above it, hence <= the true k'-th best.  A little looser than the
+// exact k'-th best of the sample (1.5 % instead of 1 % of the next pass's scores pass at kk = 40 over 4096
+// rows) but 10x cheaper than select_kth_dense_kernel (127 us at B = 1024).
+__global__ __launch_bounds__(64) void dense_lower_bound_kernel(const float* __restrict__ scores, int ld, int n, int kk,
+                                                               float* __restrict__ thr_out) {
+  const int q = blockIdx.x;
+  const int lane = threadIdx.x;
+  const float* cs = scores + (size_t)q * ld;
+  float v = -INFINITY;
+  for (int i = lane; i < n; i += 64) v = fmaxf(v, cs[i]);
+  // bitonic sort of the 64 maxima, descending by lane
+#pragma unroll
+  for (int k = 2; k <= 64; k <<= 1)
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const float o = __shfl_xor(v, j);
+      v = (((lane & j) == 0) == ((lane & k) == 0)) ? fmaxf(v, o) : fminf(v, o);
+    }
+  const float t = __shfl(v, kk - 1);
+  if (lane == 0) thr_out[q] = t;
+}
+
 }  // namespace vdbk

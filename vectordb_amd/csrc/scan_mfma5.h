@@ -181,19 +181,24 @@ __global__ __launch_bounds__(kM5Threads) void scan_mfma_wide_kernel(
   stage_a(1, 1, 0, 4);
   read_frags(0, 0, 0, 0);
 
-  // A hit waits in its lane's registers (one place per lane) until some lane needs a second place; then
-  // every waiting hit reserves its slot in its query's candidate buffer at once.  The returning atomic
-  // (~1 us, and its s_waitcnt drains the staged loads in flight too) is thus paid once per ~10 hits of
-  // the wave instead of once per hit.
-  float pend_v = 0.f;
-  int pend_row = 0, pend_q = 0;
-  bool pend_has = false;
+  // A hit waits in its lane's registers (kPend places per lane) until some lane needs one more; then every
+  // waiting hit reserves its slot in its query's candidate buffer at once.  The returning atomic (~1 us, and
+  // its s_waitcnt drains the staged loads in flight too) is thus paid once per flush, not once per hit: with
+  // one place the 1 %-hit-rate sample pass flushed at almost every hot register and ran atomics-bound.
+  constexpr int kPend = 2;
+  float pend_v[kPend];
+  int pend_row[kPend], pend_q[kPend];
+  int pend_n = 0;
+#pragma unroll
+  for (int s = 0; s < kPend; ++s) { pend_v[s] = 0.f; pend_row[s] = 0; pend_q[s] = 0; }
   auto flush_pending = [&]() {
-    if (pend_has) {
-      const int pos = atomicAdd(&cand_cnt[pend_q], 1);
-      if (pos < cap) { cand_s[(size_t)pend_q * cap + pos] = pend_v; cand_i[(size_t)pend_q * cap + pos] = pend_row; }
-    }
-    pend_has = false;
+    int pos[kPend];
+#pragma unroll
+    for (int s = 0; s < kPend; ++s) pos[s] = s < pend_n ? atomicAdd(&cand_cnt[pend_q[s]], 1) : cap;   // all in flight, one wait
+#pragma unroll
+    for (int s = 0; s < kPend; ++s)
+      if (pos[s] < cap) { cand_s[(size_t)pend_q[s] * cap + pos[s]] = pend_v[s]; cand_i[(size_t)pend_q[s] * cap + pos[s]] = pend_row[s]; }
+    pend_n = 0;
   };
   unsigned long long prof_a = 0, prof_b = 0, prof_c = 0, prof_d = 0, prof_last = 0;
   int prof_n = 0;
@@ -307,8 +312,13 @@ __global__ __launch_bounds__(kM5Threads) void scan_mfma_wide_kernel(
                 bool pass = v >= thr[nt];
                 if (needs_mask) pass = pass && (row < n_rows) && (qg < b) && !(self0 >= 0 && row == self0 + qg);
                 if (__ballot(pass) == 0ull) continue;
-                if (__ballot(pass && pend_has) != 0ull) flush_pending();   // a lane would need a second place
-                if (pass) { pend_v = v; pend_row = row; pend_q = qg; pend_has = true; }
+                if (__ballot(pass && pend_n == kPend) != 0ull) flush_pending();   // a lane has no place left
+                if (pass) {
+#pragma unroll
+                  for (int s = 0; s < kPend; ++s)
+                    if (pend_n == s) { pend_v[s] = v; pend_row[s] = row; pend_q[s] = qg; }
+                  ++pend_n;
+                }
               }
             }
           }

@@ -350,7 +350,8 @@ int mfma_search(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
                          (int*)nullptr, (float*)nullptr, (int*)nullptr, 0);
     HIP_TRY(h, hipGetLastError());
     // rows of the dense matrix beyond the sampled tiles were never written: select over t_cur*256 columns only
-    hipLaunchKernelGGL(select_kth_dense_kernel, dim3(b), dim3(1024), 0, st, dense, kMf3DenseLd, (int)t_cur * kMfBM, kk, thr);
+    // n_tiles == t_cur: the dense pass saw the whole store and the next pass is the last; either way a valid lower bound suffices
+    hipLaunchKernelGGL(dense_lower_bound_kernel, dim3(b), dim3(64), 0, st, dense, kMf3DenseLd, (int)t_cur * kMfBM, kk, thr);
     HIP_TRY(h, hipGetLastError());
   }
   // append passes over geometrically growing strided samples; the growth factor per pass is
