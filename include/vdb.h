@@ -121,6 +121,24 @@ int vdb_search(vdb_t* h, const float* queries_host, int b, int k, int rerank_kpr
 int vdb_search_dev(vdb_t* h, const float* queries_dev, int b, int k, int rerank_kprime,
                    int64_t* out_idx_dev, float* out_dist_dev, void* stream);
 
+/* Replaces collection.query(..., where=where_filter) (src/vectordb.py:230 and
+ * :259-264: find_similar_products passes its where_filter through to Chroma,
+ * which pre-filters by metadata and searches the matching rows only).  The host
+ * evaluates the metadata predicate into a bitmap, one bit per stored row of THIS
+ * handle in insertion order (bit r = word r/32, bit r%32; the row offset does
+ * not shift it): set = the row may be returned.  n_bits must equal vdb_count.
+ * The scan skips ineligible rows before top-k selection, so the result is the
+ * exact top-k of the eligible rows, -1/+inf padded when fewer than k are
+ * eligible.  Runs on the GEMV scan for every batch size. */
+int vdb_search_masked(vdb_t* h, const float* queries_host, int b, int k, int rerank_kprime,
+                      const uint32_t* allow_bits_host, int64_t n_bits,
+                      int64_t* out_idx_host, float* out_dist_host);
+
+/* Same with device-resident queries, bitmap and outputs, asynchronous on `stream`. */
+int vdb_search_masked_dev(vdb_t* h, const float* queries_dev, int b, int k, int rerank_kprime,
+                          const uint32_t* allow_bits_dev, int64_t n_bits,
+                          int64_t* out_idx_dev, float* out_dist_dev, void* stream);
+
 /* Multi-GPU merge (new in the build): after an all-gather of the
  * per-shard results, cand_* hold g lists per query laid out [g][b][k]
  * (ascending distance, idx -1 = empty); shard s starts at element

@@ -132,9 +132,10 @@ static inline void list_push(cand_t* L, int* cnt, int k, double s, int64_t i) {
 }
 
 /* Exact top-k of one normalised fp32 query against rows (fp32, or bf16 bits when
- * rows16 != NULL); fp64 accumulation; optional excluded row. Returns count. */
+ * rows16 != NULL); fp64 accumulation; optional excluded row; optional eligibility bitmap
+ * (bit r of allow set = row r may be returned). Returns count. */
 static int scan_one(const float* rows, const uint16_t* rows16, int64_t n, int dim, const float* qn,
-                    int k, int64_t exclude, cand_t* out) {
+                    int k, int64_t exclude, const uint32_t* allow, cand_t* out) {
   int nthreads = 1;
 #ifdef _OPENMP
   nthreads = omp_get_max_threads();
@@ -153,6 +154,7 @@ static int scan_one(const float* rows, const uint16_t* rows16, int64_t n, int di
     int cnt = 0;
     for (int64_t r = lo; r < hi; ++r) {
       if (r == exclude) continue;
+      if (allow && !((allow[r >> 5] >> (r & 31)) & 1u)) continue;
       double acc = 0.0;
       if (rows16) {
         const uint16_t* x = rows16 + r * dim;
@@ -180,7 +182,7 @@ void ora_search(const float* rows_norm, int64_t n, int dim, const float* queries
   cand_t* L = (cand_t*)malloc(sizeof(cand_t) * (size_t)k);
   for (int q = 0; q < b; ++q) {
     ora_normalize_rows(queries + (size_t)q * dim, qn, 1, dim);
-    int cnt = scan_one(rows_norm, NULL, n, dim, qn, k, -1, L);
+    int cnt = scan_one(rows_norm, NULL, n, dim, qn, k, -1, NULL, L);
     for (int j = 0; j < k; ++j) {
       out_idx[(size_t)q * k + j] = j < cnt ? L[j].i : -1;
       out_dist[(size_t)q * k + j] = j < cnt ? (float)(1.0 - L[j].s) : INFINITY;
@@ -284,11 +286,11 @@ static int check_search_args(vdb_t* h, const void* q, int b, int k, int kp, cons
 }
 
 /* one query through the store: scan (fp32 or bf16 rows) [+ fp32 rerank] */
-static void search_one(vdb_t* h, const float* qn, int k, int kp, int64_t exclude, int64_t* oi, float* od) {
+static void search_one(vdb_t* h, const float* qn, int k, int kp, int64_t exclude, const uint32_t* allow, int64_t* oi, float* od) {
   int kk = kp ? kp : k;
   cand_t* L = (cand_t*)malloc(sizeof(cand_t) * (size_t)kk);
   int cnt = scan_one(h->dtype == VDB_BF16 ? NULL : h->rows, h->dtype == VDB_BF16 ? h->rows16 : NULL,
-                     h->n, h->dim, qn, kk, exclude, L);
+                     h->n, h->dim, qn, kk, exclude, allow, L);
   if (kp) { /* exact fp32 re-score of the k' candidates, re-sort */
     cand_t* R = (cand_t*)malloc(sizeof(cand_t) * (size_t)kk);
     int rc = 0;
@@ -309,22 +311,39 @@ static void search_one(vdb_t* h, const float* qn, int k, int kp, int64_t exclude
   free(L);
 }
 
-int vdb_search(vdb_t* h, const float* queries, int b, int k, int kp, int64_t* out_idx, float* out_dist) {
-  if (!h) return VDB_ERR_ARG;
+static int search_all(vdb_t* h, const float* queries, int b, int k, int kp, const uint32_t* allow, int64_t* out_idx,
+                      float* out_dist) {
   int rc = check_search_args(h, queries, b, k, kp, out_idx, out_dist);
   if (rc) return rc;
   float* qn = (float*)malloc(sizeof(float) * (size_t)h->dim);
   for (int q = 0; q < b; ++q) {
     ora_normalize_rows(queries + (size_t)q * h->dim, qn, 1, h->dim);
-    search_one(h, qn, k, kp, -1, out_idx + (size_t)q * k, out_dist + (size_t)q * k);
+    search_one(h, qn, k, kp, -1, allow, out_idx + (size_t)q * k, out_dist + (size_t)q * k);
   }
   free(qn);
   h->last_bytes = (double)h->n * h->dim * (h->dtype == VDB_BF16 ? 2 : 4);
   return VDB_OK;
 }
+int vdb_search(vdb_t* h, const float* queries, int b, int k, int kp, int64_t* out_idx, float* out_dist) {
+  if (!h) return VDB_ERR_ARG;
+  return search_all(h, queries, b, k, kp, NULL, out_idx, out_dist);
+}
 int vdb_search_dev(vdb_t* h, const float* q, int b, int k, int kp, int64_t* oi, float* od, void* stream) {
   (void)stream;
   return vdb_search(h, q, b, k, kp, oi, od);
+}
+/* where-filtered query: only rows whose bit is set are eligible */
+int vdb_search_masked(vdb_t* h, const float* queries, int b, int k, int kp, const uint32_t* allow_bits, int64_t n_bits,
+                      int64_t* out_idx, float* out_dist) {
+  if (!h) return VDB_ERR_ARG;
+  if (!allow_bits && h->n > 0) return fail(h, VDB_ERR_ARG, "search_masked: NULL bitmap");
+  if (n_bits != h->n) return fail(h, VDB_ERR_ARG, "search_masked: the bitmap must hold one bit per stored row");
+  return search_all(h, queries, b, k, kp, allow_bits, out_idx, out_dist);
+}
+int vdb_search_masked_dev(vdb_t* h, const float* q, int b, int k, int kp, const uint32_t* allow_bits, int64_t n_bits,
+                          int64_t* oi, float* od, void* stream) {
+  (void)stream;
+  return vdb_search_masked(h, q, b, k, kp, allow_bits, n_bits, oi, od);
 }
 
 int vdb_merge_topk_dev(vdb_t* h, const float* cd, int64_t dstride, const int64_t* ci, int64_t istride,
@@ -364,7 +383,7 @@ int vdb_selfjoin(vdb_t* h, int64_t q0, int64_t qn_, int k, int exclude_self, int
     int64_t r = q0 + q;
     if (h->keep_f32) memcpy(qv, h->rows + r * h->dim, sizeof(float) * (size_t)h->dim);
     else for (int c = 0; c < h->dim; ++c) qv[c] = bf16_to_f32(h->rows16[r * h->dim + c]);
-    search_one(h, qv, k, kp, exclude_self ? r : -1, out_idx + (size_t)q * k, out_dist + (size_t)q * k);
+    search_one(h, qv, k, kp, exclude_self ? r : -1, NULL, out_idx + (size_t)q * k, out_dist + (size_t)q * k);
   }
   free(qv);
   return VDB_OK;

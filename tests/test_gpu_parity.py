@@ -488,3 +488,71 @@ def test_mfma_shapes_at_the_limits(hip_lib, oracle_mod, corpus20k, b, k, kp):
         assert recall_at_k(idx, r_idx) >= 0.9 and np.allclose(dist, r_dist, atol=3e-3)
         assert np.all(np.diff(dist, axis=1) >= 0)
     ix.close()
+
+
+def _masks(n, rng):
+    few = np.zeros(n, bool); few[[5, n // 2, n - 1]] = True
+    runs = (np.arange(n) // 37) % 3 == 1
+    return {"half": rng.random(n) < 0.5, "one_percent": rng.random(n) < 0.01, "runs": runs, "three_rows": few,
+            "none": np.zeros(n, bool), "all": np.ones(n, bool)}
+
+
+@pytest.mark.parametrize("dtype,kp", [("f32", 0), ("bf16", 0), ("bf16", 40)])
+def test_masked_search_equals_search_of_eligible_rows(hip_lib, oracle_mod, corpus20k, dtype, kp):
+    """where= pre-filter (src/vectordb.py:230,259-264): the masked scan returns the exact
+    top-k of the eligible rows — checked against the oracle run on those rows alone."""
+    n, dim, spec, rows, queries = corpus20k
+    rng = np.random.default_rng(17)
+    q40 = np.concatenate([queries, rows[rng.integers(0, n, 31)] + 0.05 * rng.standard_normal((31, dim)).astype(np.float32)])
+    ix = FlatIndex(dim, dtype)
+    ix.add_synth(0, n, spec)
+    src = oracle_mod.round_bf16(rows) if (dtype == "bf16" and kp == 0) else rows
+    for name, mask in _masks(n, rng).items():
+        allowed = np.flatnonzero(mask)
+        for b in (1, 3, 40):                                   # 40 would take the MFMA path unmasked; masked stays on the GEMV scan
+            q = q40[:b]
+            idx, dist = ix.search_masked(q, 10, mask, kp)
+            if name == "all":
+                i0, d0 = ix.search(q, 10, kp)
+                if b < 3:                                      # same kernel, same order of operations
+                    assert np.array_equal(idx, i0) and np.array_equal(dist, d0)
+            if allowed.size == 0:
+                assert np.all(idx == -1) and np.all(np.isinf(dist))
+                continue
+            kk = min(10, allowed.size)
+            r_idx, r_dist, r_sc = oracle_mod.exact_topk(src[allowed], q, kk)
+            assert np.all(idx[:, kk:] == -1) and np.all(np.isinf(dist[:, kk:]))
+            assert np.all(mask[idx[:, :kk]])
+            check_topk(idx[:, :kk], dist[:, :kk], allowed[r_idx], r_dist, r_sc, src, _qn(oracle_mod, q), what=f"masked {name} {dtype} b={b}")
+    with pytest.raises(Exception):
+        ix.search_masked(q40[:1], 10, np.ones(n - 1, bool))
+    ix.close()
+
+
+def test_masked_search_other_dims_and_device_entry(hip_lib, oracle_mod):
+    """generic-dim kernel (64), the 384 fast path, and vdb_search_masked_dev with a device bitmap."""
+    import torch
+    rng = np.random.default_rng(23)
+    for dim, n in ((64, 3001), (384, 5003)):
+        rows = rng.standard_normal((n, dim)).astype(np.float32)
+        rows_n = oracle_mod.normalize_rows(rows)
+        q = rows[:5] + 0.1 * rng.standard_normal((5, dim)).astype(np.float32)
+        mask = rng.random(n) < 0.3
+        allowed = np.flatnonzero(mask)
+        ix = FlatIndex(dim, "f32")
+        ix.add(rows)
+        idx, dist = ix.search_masked(q, 7, mask)
+        r_idx, r_dist, r_sc = oracle_mod.exact_topk(rows_n[allowed], q, 7)
+        check_topk(idx, dist, allowed[r_idx], r_dist, r_sc, rows_n, _qn(oracle_mod, q), what=f"masked dim={dim}")
+        bits = np.zeros(((n + 31) // 32) * 4, np.uint8)
+        packed = np.packbits(mask, bitorder="little")
+        bits[: packed.size] = packed
+        d_bits = torch.from_numpy(bits.view(np.int32)).cuda()
+        d_q = torch.from_numpy(q).cuda()
+        d_i = torch.empty((5, 7), dtype=torch.int64, device="cuda")
+        d_d = torch.empty((5, 7), dtype=torch.float32, device="cuda")
+        ix.search_masked_device(d_q.data_ptr(), 5, 7, 0, d_bits.data_ptr(), n, d_i.data_ptr(), d_d.data_ptr(),
+                                torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(d_i.cpu().numpy(), idx) and np.array_equal(d_d.cpu().numpy(), dist)
+        ix.close()

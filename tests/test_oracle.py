@@ -87,6 +87,17 @@ def test_cpu_abi_store_roundtrip(oracle_lib, oracle_mod, tmp_path):
     assert sj_idx.shape == (300, 3) and not np.any(sj_idx == np.arange(300)[:, None])
     sj2, _ = ix.selfjoin(1, exclude_self=False)
     assert np.array_equal(sj2[:, 0], np.arange(300))
+    # where= pre-filter: the masked search is the exact top-k of the eligible rows
+    mask = rng.random(300) < 0.4
+    allowed = np.flatnonzero(mask)
+    mi, md = ix.search_masked(q, 7, mask)
+    s_idx, s_dist, _ = oracle_mod.exact_topk(oracle_mod.normalize_rows(rows)[allowed], q, 7)
+    assert np.array_equal(mi, allowed[s_idx]) and np.array_equal(md, s_dist)
+    few = np.zeros(300, bool); few[[9, 200]] = True
+    mi, md = ix.search_masked(q, 7, few)
+    assert sorted(mi[0, :2].tolist()) == [9, 200] and np.all(mi[:, 2:] == -1) and np.all(np.isinf(md[:, 2:]))
+    with pytest.raises(Exception):
+        ix.search_masked(q, 7, np.ones(299, bool))
     with pytest.raises(Exception):
         ix.search(q, 0)
     with pytest.raises(Exception):

@@ -225,12 +225,21 @@ class Collection:
         return out
 
     def _query_filtered(self, q: np.ndarray, n_results: int, where: dict):
-        """Metadata pre-filter (exact): the matching rows are searched as a temporary
-        shard.  No reference caller passes `where` (src/vectordb.py:230 default None)."""
-        allowed = np.array([r for r, m in enumerate(self._metadatas) if _match_where(m, where)], dtype=np.int64)
+        """Metadata pre-filter (exact), Chroma's `where=` (src/vectordb.py:230,259-264): the
+        predicate is evaluated on the host into an eligibility bitmap and the scan skips
+        ineligible rows (vdb_search_masked).  A large batch against a very small eligible
+        set is cheaper as a temporary shard of just those rows (uploading a row costs
+        about 250 scanned rows; the masked scan serves 4 queries per corpus pass)."""
+        mask = np.fromiter((_match_where(m, where) for m in self._metadatas), dtype=np.bool_, count=len(self._metadatas))
+        allowed = np.flatnonzero(mask)
         b = q.shape[0]
         if allowed.size == 0:
             return [np.zeros(0, np.int64)] * b, [np.zeros(0, np.float32)] * b
+        if 250 * allowed.size >= ((b + 3) // 4) * mask.size:
+            k = min(n_results, allowed.size)
+            idx, dist = self._index.search_masked(q, k, mask, self._kprime(k))
+            rows = [idx[i][idx[i] >= 0] for i in range(b)]
+            return rows, [dist[i][: len(rows[i])] for i in range(b)]
         sub = FlatIndex(self._dim, self._dtype, True, self._device, lib=self._lib)
         try:
             sub.add(self._raw_matrix()[allowed])

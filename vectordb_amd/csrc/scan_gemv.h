@@ -102,12 +102,15 @@ __device__ __forceinline__ void block_merge_store(WaveTopK<E> (&tk)[QB], int kk,
 // Fast path: compile-time DIM (768, 384), QB queries per corpus pass.
 //   qn      : QB x DIM normalised fp32 queries (device)
 //   self0   : >=0 -> query q must not return row self0+q (self-join)
+//   allow   : nullptr, or the eligibility bitmap (bit r set = row r may be returned);
+//             a tile's rows lie in one 32-bit word, fetched with the tile's loads
 //   part_*  : [QB][gridDim.x][kk] partial lists
 // ---------------------------------------------------------------------------
 template <typename T, int DIM, int QB, int E, bool NT>
 __global__ __launch_bounds__(kScanThreads) void scan_topk_kernel(const void* __restrict__ rows_v, int n_rows,
                                                                   const float* __restrict__ qn, int kk,
-                                                                  int self0, float* __restrict__ part_s,
+                                                                  int self0, const unsigned* __restrict__ allow,
+                                                                  float* __restrict__ part_s,
                                                                   int* __restrict__ part_i) {
   constexpr int EPC = ElemTraits<T>::kPerChunk;   // elements per 16-byte chunk
   constexpr int CPR = DIM / EPC;                  // chunks per row
@@ -117,6 +120,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_topk_kernel(const void* __r
   constexpr int U = (L >= kScanLoadsInFlight) ? 1 : (kScanLoadsInFlight / L);     // groups per tile
   constexpr int RPT = U * R;                      // rows per tile
   static_assert(DIM % EPC == 0, "row must be a whole number of 16-byte chunks");
+  static_assert(RPT <= 32 && 32 % RPT == 0, "a tile's eligibility bits must lie in one word");
 
   const u32x4* __restrict__ rows = reinterpret_cast<const u32x4*>(rows_v);
   const int lane = lane_id();
@@ -144,6 +148,8 @@ __global__ __launch_bounds__(kScanThreads) void scan_topk_kernel(const void* __r
 
   for (long long tile = gw; tile < n_tiles; tile += nw) {
     const long long c0 = tile * (long long)(RPT * CPR) + lane;
+    const long long row0 = tile * RPT;
+    const unsigned elig = allow ? (allow[row0 >> 5] >> (unsigned)(row0 & 31)) : 0xffffffffu;
     u32x4 v[U * L];
     if ((tile + 1) * RPT <= (long long)n_rows) {
 #pragma unroll
@@ -175,8 +181,8 @@ __global__ __launch_bounds__(kScanThreads) void scan_topk_kernel(const void* __r
             else acc += (lane >= lo && lane < hi) ? p[j] : 0.f;
           }
           const float tot = wave_sum(acc);
-          const long long row = tile * RPT + u * R + r;
-          if (row < (long long)n_rows) {
+          const long long row = row0 + u * R + r;
+          if (row < (long long)n_rows && ((elig >> (u * R + r)) & 1u)) {
             const int ri = (int)row;
             const bool self = (self0 >= 0) && (ri == self0 + q);
             if (!self && tk[q].accepts(tot, ri)) tk[q].insert(tot, ri);
@@ -196,6 +202,7 @@ template <typename T, int E, bool NT>
 __global__ __launch_bounds__(kScanThreads) void scan_topk_generic_kernel(const void* __restrict__ rows_v, int n_rows,
                                                                          int ld, const float* __restrict__ qn,
                                                                          int kk, int self_row,
+                                                                         const unsigned* __restrict__ allow,
                                                                          float* __restrict__ part_s,
                                                                          int* __restrict__ part_i) {
   constexpr int EPC = ElemTraits<T>::kPerChunk;
@@ -214,6 +221,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_topk_generic_kernel(const v
   const long long gw = (long long)blockIdx.x * kScanWaves + w;
   const long long nw = (long long)gridDim.x * kScanWaves;
   for (long long row = gw; row < (long long)n_rows; row += nw) {
+    if (allow && !((allow[row >> 5] >> (unsigned)(row & 31)) & 1u)) continue;   // wave-uniform
     float acc = 0.f;
     for (int c = lane; c < cpr; c += 64) {
       const u32x4 v = load_chunk<NT>(rows + row * cpr + c);

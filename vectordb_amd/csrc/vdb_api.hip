@@ -55,6 +55,7 @@ struct vdb {
   // workspaces (grown on demand)
   DevBuf w_q, w_part_s, w_part_i, w_part2_s, w_part2_i, w_stage, w_out_i, w_out_d, w_idx, w_mfma;
   DevBuf w_cand_s, w_cand_i, w_cand_cnt, w_thr, w_dense, w_list_s, w_list_i;   // append-path state
+  DevBuf w_mask;                                                                // host-supplied eligibility bitmap (vdb_search_masked)
   int mfma_append_cap = 16384;   // candidate buffer entries per query
   int mfma_variant = 5;          // 3 = barrier ring (scan_mfma3.h), 4 = warp-specialised (scan_mfma4.h),
                                  // 5 = 256x256 tile (scan_mfma5.h) unless it pads the batch > 1.5x further, then 4
@@ -140,16 +141,16 @@ int normalize_into_store(vdb_t* h, const float* raw_dev, int in_ld, int64_t n, h
 
 // ---- scan dispatch ---------------------------------------------------------
 struct ScanArgs {
-  const void* rows; int n_rows; const float* qn; int kk; int self0; float* part_s; int* part_i;
+  const void* rows; int n_rows; const float* qn; int kk; int self0; const unsigned* allow; float* part_s; int* part_i;
   int grid; hipStream_t st; size_t smem;
 };
 
 template <typename T, int DIM, int QB, int E>
 void launch_scan_t(const ScanArgs& a, bool nt) {
   if (nt)
-    hipLaunchKernelGGL((scan_topk_kernel<T, DIM, QB, E, true>), dim3(a.grid), dim3(kScanThreads), a.smem, a.st, a.rows, a.n_rows, a.qn, a.kk, a.self0, a.part_s, a.part_i);
+    hipLaunchKernelGGL((scan_topk_kernel<T, DIM, QB, E, true>), dim3(a.grid), dim3(kScanThreads), a.smem, a.st, a.rows, a.n_rows, a.qn, a.kk, a.self0, a.allow, a.part_s, a.part_i);
   else
-    hipLaunchKernelGGL((scan_topk_kernel<T, DIM, QB, E, false>), dim3(a.grid), dim3(kScanThreads), a.smem, a.st, a.rows, a.n_rows, a.qn, a.kk, a.self0, a.part_s, a.part_i);
+    hipLaunchKernelGGL((scan_topk_kernel<T, DIM, QB, E, false>), dim3(a.grid), dim3(kScanThreads), a.smem, a.st, a.rows, a.n_rows, a.qn, a.kk, a.self0, a.allow, a.part_s, a.part_i);
 }
 
 template <typename T, int DIM>
@@ -180,8 +181,8 @@ template <typename T>
 bool launch_scan_generic(const ScanArgs& a, int ld, int e, bool nt) {
 #define GEN_CASE(EE)                                                                                              \
   case EE:                                                                                                        \
-    if (nt) hipLaunchKernelGGL((scan_topk_generic_kernel<T, EE, true>), dim3(a.grid), dim3(kScanThreads), a.smem, a.st, a.rows, a.n_rows, ld, a.qn, a.kk, a.self0, a.part_s, a.part_i); \
-    else hipLaunchKernelGGL((scan_topk_generic_kernel<T, EE, false>), dim3(a.grid), dim3(kScanThreads), a.smem, a.st, a.rows, a.n_rows, ld, a.qn, a.kk, a.self0, a.part_s, a.part_i);   \
+    if (nt) hipLaunchKernelGGL((scan_topk_generic_kernel<T, EE, true>), dim3(a.grid), dim3(kScanThreads), a.smem, a.st, a.rows, a.n_rows, ld, a.qn, a.kk, a.self0, a.allow, a.part_s, a.part_i); \
+    else hipLaunchKernelGGL((scan_topk_generic_kernel<T, EE, false>), dim3(a.grid), dim3(kScanThreads), a.smem, a.st, a.rows, a.n_rows, ld, a.qn, a.kk, a.self0, a.allow, a.part_s, a.part_i);   \
     return true;
   switch (e) { GEN_CASE(1) GEN_CASE(2) GEN_CASE(4) GEN_CASE(8) GEN_CASE(16) }
 #undef GEN_CASE
@@ -425,8 +426,9 @@ bool mfma_is_faster(int b, int n_rows) {
 
 // Core search over device-resident, already *normalised* queries qn [b][ld].
 // self_row0 >= 0: query q excludes row self_row0+q.
+// allow != nullptr: device bitmap of eligible rows (GEMV scan only).
 int search_core(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_row0, int64_t* out_idx,
-                float* out_dist, hipStream_t st) {
+                float* out_dist, hipStream_t st, const unsigned* allow = nullptr) {
   const int kk = kp ? kp : k;
   const int e = entries_for(kk);
   const bool bf16 = h->dtype == VDB_BF16;
@@ -450,7 +452,7 @@ int search_core(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
   }
 
   // MFMA batched path (bf16 store, fast dim, enough queries that it beats ceil(b/4) GEMV passes)
-  if (bf16 && h->dim == 768 && h->ld == 768 && b >= h->batch_mfma_min_b && mfma_path_supported(kk) && n_rows >= 4096 &&
+  if (!allow && bf16 && h->dim == 768 && h->ld == 768 && b >= h->batch_mfma_min_b && mfma_path_supported(kk) && n_rows >= 4096 &&
       (!h->mfma_cost_model || mfma_is_faster(b, n_rows))) {
     int rc = mfma_search(h, qn, b, k, kp, self_row0, out_idx, out_dist, st);
     return rc;
@@ -481,6 +483,7 @@ int search_core(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
       ScanArgs a;
       a.rows = rows; a.n_rows = n_rows; a.qn = qn + (size_t)(q0 + q) * h->ld; a.kk = kk;
       a.self0 = self_row0 >= 0 ? (int)(self_row0 + q0 + q) : -1;
+      a.allow = allow;
       a.part_s = (float*)h->w_part_s.p + (size_t)q * grid * kk;
       a.part_i = (int*)h->w_part_i.p + (size_t)q * grid * kk;
       a.grid = grid; a.st = st;
@@ -574,7 +577,7 @@ void vdb_destroy(vdb_t* h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   DevBuf* bufs[] = {&h->w_q, &h->w_part_s, &h->w_part_i, &h->w_part2_s, &h->w_part2_i, &h->w_stage, &h->w_out_i, &h->w_out_d, &h->w_idx, &h->w_mfma,
-                    &h->w_cand_s, &h->w_cand_i, &h->w_cand_cnt, &h->w_thr, &h->w_dense, &h->w_list_s, &h->w_list_i};
+                    &h->w_cand_s, &h->w_cand_i, &h->w_cand_cnt, &h->w_thr, &h->w_dense, &h->w_list_s, &h->w_list_i, &h->w_mask};
   for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
   if (h->rows_f32) (void)hipFree(h->rows_f32);
   if (h->rows_bf16) (void)hipFree(h->rows_bf16);
@@ -664,6 +667,47 @@ int vdb_search(vdb_t* h, const float* queries_host, int b, int k, int kp, int64_
   float* qn = nullptr;
   if ((rc = prep_queries(h, (const float*)h->w_stage.p, b, h->stream, &qn))) return rc;
   if ((rc = search_core(h, qn, b, k, kp, -1, (int64_t*)h->w_out_i.p, (float*)h->w_out_d.p, h->stream))) return rc;
+  HIP_TRY(h, hipMemcpyAsync(out_idx, h->w_out_i.p, (size_t)b * k * 8, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(out_dist, h->w_out_d.p, (size_t)b * k * 4, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return VDB_OK;
+}
+
+int vdb_search_masked_dev(vdb_t* h, const float* queries_dev, int b, int k, int kp, const uint32_t* allow_dev,
+                          int64_t n_bits, int64_t* out_idx_dev, float* out_dist_dev, void* stream) {
+  if (!h) return VDB_ERR_ARG;
+  if (!allow_dev && h->n > 0) return fail(h, VDB_ERR_ARG, "search_masked: NULL bitmap");
+  if (n_bits != h->n) return fail(h, VDB_ERR_ARG, "search_masked: the bitmap must hold one bit per stored row");
+  int rc = check_search_args(h, queries_dev, b, k, kp, out_idx_dev, out_dist_dev);
+  if (rc) return rc;
+  if (b == 0) return VDB_OK;
+  if ((rc = set_device(h))) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  float* qn = nullptr;
+  if ((rc = prep_queries(h, queries_dev, b, st, &qn))) return rc;
+  return search_core(h, qn, b, k, kp, -1, out_idx_dev, out_dist_dev, st, allow_dev);
+}
+
+int vdb_search_masked(vdb_t* h, const float* queries_host, int b, int k, int kp, const uint32_t* allow_host,
+                      int64_t n_bits, int64_t* out_idx, float* out_dist) {
+  if (!h) return VDB_ERR_ARG;
+  if (!allow_host && h->n > 0) return fail(h, VDB_ERR_ARG, "search_masked: NULL bitmap");
+  if (n_bits != h->n) return fail(h, VDB_ERR_ARG, "search_masked: the bitmap must hold one bit per stored row");
+  int rc = check_search_args(h, queries_host, b, k, kp, out_idx, out_dist);
+  if (rc) return rc;
+  if (b == 0) return VDB_OK;
+  if ((rc = set_device(h))) return rc;
+  const size_t words = (size_t)((h->n + 31) / 32);
+  if ((rc = ensure(h, h->w_mask, std::max<size_t>(words, 1) * 4))) return rc;
+  if ((rc = ensure(h, h->w_stage, (size_t)b * h->dim * 4))) return rc;
+  if ((rc = ensure(h, h->w_out_i, (size_t)b * k * 8))) return rc;
+  if ((rc = ensure(h, h->w_out_d, (size_t)b * k * 4))) return rc;
+  if (words) HIP_TRY(h, hipMemcpyAsync(h->w_mask.p, allow_host, words * 4, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(h->w_stage.p, queries_host, (size_t)b * h->dim * 4, hipMemcpyHostToDevice, h->stream));
+  float* qn = nullptr;
+  if ((rc = prep_queries(h, (const float*)h->w_stage.p, b, h->stream, &qn))) return rc;
+  if ((rc = search_core(h, qn, b, k, kp, -1, (int64_t*)h->w_out_i.p, (float*)h->w_out_d.p, h->stream,
+                        (const unsigned*)h->w_mask.p))) return rc;
   HIP_TRY(h, hipMemcpyAsync(out_idx, h->w_out_i.p, (size_t)b * k * 8, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipMemcpyAsync(out_dist, h->w_out_d.p, (size_t)b * k * 4, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));

@@ -105,6 +105,31 @@ class FlatIndex:
                                        idx.ctypes.data, dist.ctypes.data))
         return idx, dist
 
+    def search_masked(self, queries, k: int, allow, rerank_kprime: int = 0) -> Tuple[np.ndarray, np.ndarray]:
+        """Exact top-k over the rows `allow` marks eligible (the `where=` pre-filter of
+        collection.query, reference src/vectordb.py:230,259-264).  allow: boolean array,
+        one entry per stored row."""
+        q = _as_f32_2d(queries, self.dim, "queries")
+        allow = np.asarray(allow)
+        n = self.count()
+        if allow.dtype != np.bool_ or allow.shape != (n,):
+            raise ValueError(f"allow must be a boolean array of shape ({n},), got {allow.dtype} {allow.shape}")
+        bits = np.packbits(allow, bitorder="little")
+        words = np.zeros(max(1, (n + 31) // 32) * 4, np.uint8)
+        words[: bits.size] = bits
+        b = q.shape[0]
+        idx = np.empty((b, k), np.int64)
+        dist = np.empty((b, k), np.float32)
+        self._chk(self._lib.vdb_search_masked(self._h, q.ctypes.data, b, int(k), int(rerank_kprime), words.ctypes.data, n,
+                                              idx.ctypes.data, dist.ctypes.data))
+        return idx, dist
+
+    def search_masked_device(self, q_ptr: int, b: int, k: int, rerank_kprime: int, allow_bits_ptr: int, n_bits: int,
+                             out_idx_ptr: int, out_dist_ptr: int, stream: int = 0) -> None:
+        self._chk(self._lib.vdb_search_masked_dev(self._h, int(q_ptr), int(b), int(k), int(rerank_kprime),
+                                                  int(allow_bits_ptr), int(n_bits), int(out_idx_ptr), int(out_dist_ptr),
+                                                  stream or None))
+
     def search_device(self, q_ptr: int, b: int, k: int, rerank_kprime: int, out_idx_ptr: int,
                       out_dist_ptr: int, stream: int = 0) -> None:
         self._chk(self._lib.vdb_search_dev(self._h, int(q_ptr), int(b), int(k), int(rerank_kprime),
