@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <vector>
 
+static int g_blocks = 256;   // argv[1]: fewer blocks = fewer CUs pulling from each XCD's L2
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
 __device__ __forceinline__ void glds16(const unsigned char* g, unsigned char* l) {
@@ -73,6 +74,73 @@ __global__ __launch_bounds__(512) void probe(const unsigned char* __restrict__ s
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// Register staging of the same 128-B-segment pattern: global_load_dwordx4 into VGPRs, one stage (SLOTS KiB per
+// wave) kept in flight, then ds_write_b128 into LDS (TO_LDS = 1) or folded into a checksum (TO_LDS = 0).
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+template <int SLOTS, int TO_LDS>
+__global__ __launch_bounds__(512) void probe_regs(const unsigned char* __restrict__ src, long long n_rows, int n_stages,
+                                                  int rows_per_block_stage, unsigned* __restrict__ sink) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int xcd = blockIdx.x & 7;
+  const long long xcd_rows = n_rows / 8;
+  const unsigned char* base = src + (size_t)xcd * xcd_rows * 1536;
+  const unsigned lane_off = (unsigned)((lane / 8) * 1536 + (lane % 8) * 16);
+  u32x4_t buf[2][SLOTS];
+  u32x4_t acc = {0u, 0u, 0u, 0u};
+  auto issue = [&](int stage, u32x4_t* dst) {
+    const int ks = stage % 12;
+    const long long win = ((long long)(stage / 12) * rows_per_block_stage) % (xcd_rows - rows_per_block_stage);
+    const unsigned char* p = base + (size_t)win * 1536 + (size_t)ks * 128 + (size_t)w * SLOTS * 8 * 1536;
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i)
+      dst[i] = *reinterpret_cast<const u32x4_t*>(p + (size_t)i * 8 * 1536 + lane_off);
+  };
+  auto consume = [&](int stage, u32x4_t* v) {
+    if (TO_LDS) {
+      unsigned char* st = smem + ((stage & 1) * 8 + w) * SLOTS * 1024;
+#pragma unroll
+      for (int i = 0; i < SLOTS; ++i) *reinterpret_cast<u32x4_t*>(st + i * 1024 + lane * 16) = v[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < SLOTS; ++i) acc ^= v[i];
+    }
+  };
+  issue(0, buf[0]);
+  for (int s = 0; s < n_stages; s += 2) {
+    issue(s + 1, buf[1]);
+    consume(s, buf[0]);          // the compiler waits for exactly the older stage's loads (vmcnt = SLOTS)
+    __builtin_amdgcn_s_barrier();
+    issue(s + 2, buf[0]);
+    consume(s + 1, buf[1]);
+    __builtin_amdgcn_s_barrier();
+  }
+  consume(0, buf[0]);
+  if (TO_LDS) { __syncthreads(); acc.x = *reinterpret_cast<unsigned*>(smem + threadIdx.x * 4); }
+  if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) sink[threadIdx.x] = acc.x;
+}
+
+template <int SLOTS, int TO_LDS>
+void run_regs(const unsigned char* d, long long n_rows, unsigned* sink, const char* what) {
+  const int n_stages = 6000;
+  const int rows_per_block_stage = 8 * SLOTS * 8;
+  const size_t smem = (size_t)2 * 8 * SLOTS * 1024;
+  CHECK(hipFuncSetAttribute((const void*)probe_regs<SLOTS, TO_LDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  for (int rep = 0; rep < 2; ++rep) {
+    CHECK(hipEventRecord(e0));
+    hipLaunchKernelGGL((probe_regs<SLOTS, TO_LDS>), dim3(g_blocks), dim3(512), smem, 0, d, n_rows, n_stages, rows_per_block_stage, sink);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+  }
+  float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+  const double bytes = (double)g_blocks * n_stages * 8 * SLOTS * 1024;
+  printf("%-34s seg 128 B  kept in flight/CU %3d KiB  stage %2d KiB : %6.2f ms  %6.2f TB/s  %5.1f GB/s per CU\n", what,
+         8 * SLOTS, 8 * SLOTS, ms, bytes / ms / 1e9, bytes / ms / 1e6 / g_blocks);
+}
+
 template <int SEG, int KEEP, int SLOTS, int PRIVATE = 0>
 void run(const unsigned char* d, long long n_rows, const char* what) {
   const int n_stages = 6000;
@@ -83,17 +151,20 @@ void run(const unsigned char* d, long long n_rows, const char* what) {
   CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
   for (int rep = 0; rep < 2; ++rep) {
     CHECK(hipEventRecord(e0));
-    hipLaunchKernelGGL((probe<SEG, KEEP, SLOTS, PRIVATE>), dim3(256), dim3(512), smem, 0, d, n_rows, n_stages, rows_per_block_stage);
+    hipLaunchKernelGGL((probe<SEG, KEEP, SLOTS, PRIVATE>), dim3(g_blocks), dim3(512), smem, 0, d, n_rows, n_stages, rows_per_block_stage);
     CHECK(hipEventRecord(e1));
     CHECK(hipEventSynchronize(e1));
   }
   float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
-  const double bytes = 256.0 * n_stages * 8 * SLOTS * 1024;
+  const double bytes = (double)g_blocks * n_stages * 8 * SLOTS * 1024;
   printf("%-34s seg %3d B  kept in flight/CU %3d KiB  stage %2d KiB : %6.2f ms  %6.2f TB/s  %5.1f GB/s per CU\n", what, SEG,
-         KEEP * 8 * SLOTS, 8 * SLOTS, ms, bytes / ms / 1e9, bytes / ms / 1e6 / 256);
+         KEEP * 8 * SLOTS, 8 * SLOTS, ms, bytes / ms / 1e9, bytes / ms / 1e6 / g_blocks);
 }
 
-int main() {
+int main(int argc, char** argv) {
+  if (argc > 1) g_blocks = atoi(argv[1]);
+  if (g_blocks < 8 || g_blocks > 256) { printf("blocks must be in [8,256]\n"); return 1; }
+  printf("%d blocks (one per CU)\n", g_blocks);
   const long long n_rows = 1 << 20;   // 1.5 GiB matrix
   unsigned char* d;
   CHECK(hipMalloc(&d, (size_t)n_rows * 1536));
@@ -109,6 +180,13 @@ int main() {
   run<64, 1, 4>(d, n_rows, "32 KiB half-line stages, 1 kept");
   run<64, 2, 4>(d, n_rows, "32 KiB half-line stages, 2 kept");
   run<64, 3, 4>(d, n_rows, "32 KiB half-line stages, 3 kept");
+  unsigned* sink;
+  CHECK(hipMalloc(&sink, 4096));
+  run_regs<8, 0>(d, n_rows, sink, "regs only, 64 KiB stages, 1 kept");
+  run_regs<8, 1>(d, n_rows, sink, "regs -> ds_write, 64 KiB, 1 kept");
+  run_regs<4, 0>(d, n_rows, sink, "regs only, 32 KiB stages, 1 kept");
+  run_regs<4, 1>(d, n_rows, sink, "regs -> ds_write, 32 KiB, 1 kept");
+  CHECK(hipFree(sink));
   CHECK(hipFree(d));
   return 0;
 }
