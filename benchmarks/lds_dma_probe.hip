@@ -22,11 +22,13 @@
 static int g_blocks = 256;   // argv[1]: fewer blocks = fewer CUs pulling from each XCD's L2
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
+// AUX = cache-policy bits of the load: 1 = sc0, 2 = nt, 16 = sc1
+template <int AUX = 0>
 __device__ __forceinline__ void glds16(const unsigned char* g, unsigned char* l) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, AUX);
 }
 
-template <int SEG, int KEEP, int SLOTS, int PRIVATE = 0>
+template <int SEG, int KEEP, int SLOTS, int PRIVATE = 0, int AUX = 0>
 __global__ __launch_bounds__(512) void probe(const unsigned char* __restrict__ src, long long n_rows, int n_stages, int rows_per_block_stage) {
   extern __shared__ __align__(16) unsigned char smem[];
   constexpr int RING = KEEP + 1;
@@ -49,13 +51,13 @@ __global__ __launch_bounds__(512) void probe(const unsigned char* __restrict__ s
       const unsigned char* reg = src + (size_t)blockIdx.x * (96 << 10);
       const size_t off = ((size_t)stage * 8 * SLOTS * 1024) % (96 << 10);
 #pragma unroll
-      for (int i = 0; i < SLOTS; ++i) glds16(reg + (off + (size_t)(w * SLOTS + i) * 1024) % (96 << 10) + lane * 16, st + i * 1024);
+      for (int i = 0; i < SLOTS; ++i) glds16<AUX>(reg + (off + (size_t)(w * SLOTS + i) * 1024) % (96 << 10) + lane * 16, st + i * 1024);
       return;
     }
     const long long win = ((long long)(stage / KSTEPS) * rows_per_block_stage) % (xcd_rows - rows_per_block_stage);
     const unsigned char* p = base + (size_t)win * 1536 + (size_t)ks * SEG + (size_t)w * SLOTS * ROWS_PER_PIECE * 1536;
 #pragma unroll
-    for (int i = 0; i < SLOTS; ++i) glds16(p + (size_t)i * ROWS_PER_PIECE * 1536 + lane_off, st + i * 1024);
+    for (int i = 0; i < SLOTS; ++i) glds16<AUX>(p + (size_t)i * ROWS_PER_PIECE * 1536 + lane_off, st + i * 1024);
   };
 #pragma unroll
   for (int s = 0; s < KEEP; ++s) issue(s);
@@ -141,17 +143,17 @@ void run_regs(const unsigned char* d, long long n_rows, unsigned* sink, const ch
          8 * SLOTS, 8 * SLOTS, ms, bytes / ms / 1e9, bytes / ms / 1e6 / g_blocks);
 }
 
-template <int SEG, int KEEP, int SLOTS, int PRIVATE = 0>
+template <int SEG, int KEEP, int SLOTS, int PRIVATE = 0, int AUX = 0>
 void run(const unsigned char* d, long long n_rows, const char* what) {
   const int n_stages = 6000;
   const int rows_per_block_stage = 8 * SLOTS * (1024 / SEG);   // rows one block covers per stage
   const size_t smem = (size_t)(KEEP + 1) * 8 * SLOTS * 1024;
-  CHECK(hipFuncSetAttribute((const void*)probe<SEG, KEEP, SLOTS, PRIVATE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  CHECK(hipFuncSetAttribute((const void*)probe<SEG, KEEP, SLOTS, PRIVATE, AUX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
   for (int rep = 0; rep < 2; ++rep) {
     CHECK(hipEventRecord(e0));
-    hipLaunchKernelGGL((probe<SEG, KEEP, SLOTS, PRIVATE>), dim3(g_blocks), dim3(512), smem, 0, d, n_rows, n_stages, rows_per_block_stage);
+    hipLaunchKernelGGL((probe<SEG, KEEP, SLOTS, PRIVATE, AUX>), dim3(g_blocks), dim3(512), smem, 0, d, n_rows, n_stages, rows_per_block_stage);
     CHECK(hipEventRecord(e1));
     CHECK(hipEventSynchronize(e1));
   }
@@ -180,6 +182,11 @@ int main(int argc, char** argv) {
   run<64, 1, 4>(d, n_rows, "32 KiB half-line stages, 1 kept");
   run<64, 2, 4>(d, n_rows, "32 KiB half-line stages, 2 kept");
   run<64, 3, 4>(d, n_rows, "32 KiB half-line stages, 3 kept");
+  run<128, 1, 8, 0, 1>(d, n_rows, "64 KiB stages, 1 kept, sc0");
+  run<128, 1, 8, 0, 2>(d, n_rows, "64 KiB stages, 1 kept, nt");
+  run<128, 1, 8, 0, 3>(d, n_rows, "64 KiB stages, 1 kept, sc0 nt");
+  run<128, 1, 8, 0, 16>(d, n_rows, "64 KiB stages, 1 kept, sc1");
+  run<128, 1, 8, 0, 17>(d, n_rows, "64 KiB stages, 1 kept, sc0 sc1");
   unsigned* sink;
   CHECK(hipMalloc(&sink, 4096));
   run_regs<8, 0>(d, n_rows, sink, "regs only, 64 KiB stages, 1 kept");
