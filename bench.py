@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--sync-exchange", action="store_true", help="diagnostic: wait for each batch's exchange (no overlap)")
     ap.add_argument("--mfma-min-b", type=int, default=0, help="diagnostic: smallest batch sent to the MFMA path")
     ap.add_argument("--clusters", type=int, default=0, help="synthetic clusters (default sqrt(rows))")
+    ap.add_argument("--time-every", type=int, default=4, help="HIP-event timing of the kernel on every Nth step (an event record idles the queue ~6 us)")
     ap.add_argument("--ablate", type=int, default=0, help="diagnostic: MFMA kernel ablation bits (results invalid)")
     args = ap.parse_args()
 
@@ -153,6 +154,7 @@ def main():
         step(i)
     torch.cuda.synchronize()
     sh.local.set_option("timing_ring", max(1, min(args.steps, 65536)))
+    sh.local.set_option("timing_every", max(1, args.time_every))
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -165,6 +167,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     tstats = sh.local.timing_stats()
+    sh.local.set_option("timing_every", 1)
     # outside the timed region: per-call latency with a sync after every call (median and p99)
     lat = []
     for i in range(min(args.steps, 100)):
@@ -228,6 +231,7 @@ def main():
         wide = mfma and 2 * (((b + 255) // 256) * 256) <= 3 * (((b + 127) // 128) * 128)
         roof["kernel"] = ("scan_mfma_wide_kernel<1> + sample passes" if wide else "scan_mfma_ws_kernel<1> + sample passes") if mfma else "scan_topk_kernel"
         roof["kernel_avg_ms"] = scan_ms
+        roof["kernel_timing"] = f"HIP events around the kernel on every {max(1, args.time_every)}th step of the timed region ({tstats['n']} samples)"
         roof["merge_rerank_avg_ms"] = tstats["merge_ms_sum"] / max(tstats["n"], 1)
         out = {
             "metric": f"QPS @k={k}, {n // 1_000_000}Mx{dim} corpus, batch {b}",

@@ -182,7 +182,7 @@ int vdb_last_timing(vdb_t* h, float* scan_ms, float* merge_ms, double* bytes_str
  * region without synchronising between steps.  reset != 0 restarts the count. */
 int vdb_timing_stats(vdb_t* h, int64_t* n_searches, double* scan_ms_sum, double* merge_ms_sum, int reset);
 
-/* Tuning knobs: "timing_ring", "scan_blocks_per_cu", "scan_nt_loads", "batch_mfma_min_b" (default 3),
+/* Tuning knobs: "timing_ring", "timing_every" (record the timing events on every Nth search only; default 1), "scan_blocks_per_cu", "scan_nt_loads", "batch_mfma_min_b" (default 3),
  * "mfma_cost_model" (default 1: a batch takes the MFMA path only where it is faster than ceil(b/4) GEMV passes;
  * 0: whenever it is supported), "mfma_variant", "mfma_append_cap", "mfma_force_fallback".
  * Unknown names return VDB_ERR_ARG. */

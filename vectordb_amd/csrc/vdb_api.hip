@@ -43,6 +43,9 @@ struct vdb {
   hipEvent_t* ev = nullptr;       // triple of the search in flight
   int64_t n_timed = 0;            // searches recorded since the ring was (re)set
   bool timing_valid = false;
+  int timing_every = 1;           // record the three events on every Nth search only (an event record idles the queue ~6 us)
+  int64_t n_calls = 0;
+  bool ev_on = true;              // this search is a timed one
   double last_bytes = 0.0;
   int n_cu = 256;
   // options
@@ -394,7 +397,7 @@ int mfma_search(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
                      n_qt_fb, fb.n_splits, fb.tiles_per_split, kk, self0, fb.xcd_map, h->mfma_ablate, (const int*)ovf,
                      (float*)h->w_part_s.p, (int*)h->w_part_i.p);
   HIP_TRY(h, hipGetLastError());
-  HIP_TRY(h, hipEventRecord(h->ev[1], st));
+  if (h->ev_on) HIP_TRY(h, hipEventRecord(h->ev[1], st));
   if (kp)
     hipLaunchKernelGGL((final_sorted_kernel<true>), dim3(b), dim3(1024), 0, st, (const float*)list_s, (const int*)list_i, 1, kk, k,
                        (long long)h->row_offset, (const float*)h->rows_f32, h->ld, qn, (long long*)out_idx, out_dist,
@@ -404,8 +407,8 @@ int mfma_search(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
                        (long long)h->row_offset, (const float*)nullptr, h->ld, qn, (long long*)out_idx, out_dist,
                        (const int*)ovf, (const float*)h->w_part_s.p, (const int*)h->w_part_i.p, fb.n_splits);
   HIP_TRY(h, hipGetLastError());
-  HIP_TRY(h, hipEventRecord(h->ev[2], st));
-  h->timing_valid = true;
+  if (h->ev_on) HIP_TRY(h, hipEventRecord(h->ev[2], st));
+  if (h->ev_on) h->timing_valid = true;
   return VDB_OK;
 }
 
@@ -436,18 +439,22 @@ int search_core(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
   const int n_rows = (int)h->n;
   const bool fast_dim = (h->ld == h->dim) && (h->dim == 768 || h->dim == 384);
 
-  h->ev = h->ring.data() + 3 * (size_t)(h->n_timed % (int64_t)(h->ring.size() / 3));
-  h->n_timed++;
-  HIP_TRY(h, hipEventRecord(h->ev[0], st));
+  h->ev_on = h->timing_every <= 1 || (h->n_calls % h->timing_every) == 0;
+  h->n_calls++;
+  if (h->ev_on) {
+    h->ev = h->ring.data() + 3 * (size_t)(h->n_timed % (int64_t)(h->ring.size() / 3));
+    h->n_timed++;
+    HIP_TRY(h, hipEventRecord(h->ev[0], st));
+  }
   h->last_bytes = 0.0;
 
   if (n_rows == 0) {
     // empty store: all -1 / +inf
     hipLaunchKernelGGL(fill_empty_kernel, dim3((b * k + 255) / 256), dim3(256), 0, st, (long long*)out_idx, out_dist, (long long)b * k);
     HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, hipEventRecord(h->ev[1], st));
-    HIP_TRY(h, hipEventRecord(h->ev[2], st));
-    h->timing_valid = true;
+    if (h->ev_on) HIP_TRY(h, hipEventRecord(h->ev[1], st));
+    if (h->ev_on) HIP_TRY(h, hipEventRecord(h->ev[2], st));
+    if (h->ev_on) h->timing_valid = true;
     return VDB_OK;
   }
 
@@ -502,14 +509,14 @@ int search_core(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
       h->last_bytes += (double)n_rows * h->ld * (bf16 ? 2 : 4);
       q += qb;
     }
-    if (q0 == 0 && b <= qchunk) HIP_TRY(h, hipEventRecord(h->ev[1], st));
+    if (q0 == 0 && b <= qchunk) if (h->ev_on) HIP_TRY(h, hipEventRecord(h->ev[1], st));
     // --- merge + finish ----------------------------------------------------
     if ((rc = finish_search(h, cb, grid, kk, k, kp, qn + (size_t)q0 * h->ld, out_idx + (size_t)q0 * k,
                             out_dist + (size_t)q0 * k, st))) return rc;
   }
-  if (b > qchunk) HIP_TRY(h, hipEventRecord(h->ev[1], st));  // multi-chunk: scan/merge interleave, report total as scan
-  HIP_TRY(h, hipEventRecord(h->ev[2], st));
-  h->timing_valid = true;
+  if (b > qchunk) if (h->ev_on) HIP_TRY(h, hipEventRecord(h->ev[1], st));  // multi-chunk: scan/merge interleave, report total as scan
+  if (h->ev_on) HIP_TRY(h, hipEventRecord(h->ev[2], st));
+  if (h->ev_on) h->timing_valid = true;
   return VDB_OK;
 }
 
@@ -908,6 +915,10 @@ int vdb_set_option(vdb_t* h, const char* name, int64_t value) {
     if (rc) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return resize_ring(h, (int)value);
+  }
+  if (!strcmp(name, "timing_every")) {
+    if (value < 1 || value > 65536) return fail(h, VDB_ERR_ARG, "timing_every must be in [1,65536]");
+    h->timing_every = (int)value; h->n_calls = 0; return VDB_OK;
   }
   if (!strcmp(name, "scan_nt_loads")) { h->scan_nt_loads = value != 0; return VDB_OK; }
   if (!strcmp(name, "mfma_ablate")) { h->mfma_ablate = (int)value; return VDB_OK; }
