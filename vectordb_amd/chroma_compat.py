@@ -142,7 +142,18 @@ class Collection:
             if documents is None:
                 raise ValueError("You must provide either embeddings or documents")
             embeddings = self._embed([documents] if isinstance(documents, str) else documents)
-        emb = np.asarray(embeddings, dtype=np.float32)
+        dev_emb = None
+        if getattr(embeddings, "is_cuda", False) and self._lib is None:
+            # a torch tensor already on the GPU (an embedder's output): it is handed to the engine in place
+            # (vdb_add_dev); the host copy below only feeds get(include=["embeddings"]) and persist()
+            dev_emb = embeddings.detach().float().contiguous()
+            if dev_emb.ndim == 1:
+                dev_emb = dev_emb.reshape(1, -1)
+            emb = dev_emb.cpu().numpy()
+        else:
+            if hasattr(embeddings, "detach"):
+                embeddings = embeddings.detach().cpu().numpy()
+            emb = np.asarray(embeddings, dtype=np.float32)
         if emb.ndim == 1:
             emb = emb.reshape(1, -1)
         if emb.ndim != 2 or emb.shape[0] != n:
@@ -162,8 +173,15 @@ class Collection:
             return
         if len(keep) != n:
             emb = emb[keep]
+            if dev_emb is not None:
+                dev_emb = dev_emb[keep].contiguous()
         index = self._ensure_index(emb.shape[1])
-        index.add(emb)
+        if dev_emb is not None and dev_emb.device.index == index.device:
+            import torch
+            torch.cuda.current_stream(dev_emb.device).synchronize()     # the engine ingests on its own stream
+            index.add_device(dev_emb.data_ptr(), dev_emb.shape[0])
+        else:
+            index.add(emb)
         base = len(self._ids)
         for off, j in enumerate(keep):
             self._id_to_row[ids[j]] = base + off

@@ -51,7 +51,10 @@ class MPNetEmbedder:
     """sentence-transformers/all-mpnet-base-v2 semantics from a LOCAL directory:
     tokenizer + MPNetModel -> attention-masked mean pooling -> L2 normalise."""
 
-    def __init__(self, local_dir: str, device: str = None, batch_size: int = 64, max_length: int = 384):
+    def __init__(self, local_dir: str, device: str = None, batch_size: int = 64, max_length: int = 384,
+                 autocast: str = None):
+        """autocast: None (fp32 forward, the reference's precision), "bf16" or "fp16" (GPU only; the
+        pooled vector is still accumulated and normalised in fp32)."""
         import torch
         from transformers import AutoModel, AutoTokenizer
         if not os.path.isdir(local_dir):
@@ -62,21 +65,32 @@ class MPNetEmbedder:
         self.model = AutoModel.from_pretrained(local_dir, local_files_only=True).to(self.device).eval()
         self.batch_size = batch_size
         self.max_length = max_length
+        if autocast not in (None, "bf16", "fp16"):
+            raise ValueError("autocast must be None, 'bf16' or 'fp16'")
+        self._amp = {None: None, "bf16": torch.bfloat16, "fp16": torch.float16}[autocast]
+        self.dim = int(self.model.config.hidden_size)
 
-    def __call__(self, texts: Sequence[str]) -> List[np.ndarray]:
+    def embed_device(self, texts: Sequence[str]):
+        """-> torch.Tensor [n, dim] fp32 on self.device, rows unit length.  On a GPU the result can go
+        straight into the store (Collection.add accepts it; vdb_add_dev) without the host round trip
+        of the reference's `embeddings.tolist()` (src/vectordb.py:216)."""
         torch = self._torch
-        out: List[np.ndarray] = []
         texts = list(texts)
+        out = torch.empty((len(texts), self.dim), dtype=torch.float32, device=self.device)
+        dev_type = "cuda" if str(self.device).startswith("cuda") else "cpu"
         with torch.no_grad():
             for i in range(0, len(texts), self.batch_size):
                 enc = self.tok(texts[i:i + self.batch_size], padding=True, truncation=True,
                                max_length=self.max_length, return_tensors="pt").to(self.device)
-                hid = self.model(**enc).last_hidden_state
-                mask = enc["attention_mask"].unsqueeze(-1).to(hid.dtype)
-                pooled = (hid * mask).sum(1) / mask.sum(1).clamp(min=1e-9)
-                pooled = torch.nn.functional.normalize(pooled, p=2, dim=1)
-                out.extend(pooled.float().cpu().numpy())
+                with torch.autocast(dev_type, dtype=self._amp, enabled=self._amp is not None and dev_type == "cuda"):
+                    hid = self.model(**enc).last_hidden_state
+                mask = enc["attention_mask"].unsqueeze(-1).float()
+                pooled = (hid.float() * mask).sum(1) / mask.sum(1).clamp(min=1e-9)
+                out[i:i + self.batch_size] = torch.nn.functional.normalize(pooled, p=2, dim=1)
         return out
+
+    def __call__(self, texts: Sequence[str]) -> List[np.ndarray]:
+        return list(self.embed_device(texts).cpu().numpy())
 
 
 def SentenceTransformerEmbeddingFunction(model_name: str = "all-mpnet-base-v2", **_ignored):

@@ -54,6 +54,20 @@ class ProductEmbedder:
         ids = [f"item_{i}" for i in range(len(df))]          # positional ids, src/vectordb.py:57
         return ids, embeddings, self._prepare_metadata(df)
 
+    def embed_products_device(self, df: pd.DataFrame):
+        """embed_products with the embeddings left on the GPU as one [n, dim] tensor (embedders that
+        offer embed_device on a CUDA device only) — the ingest then skips the host round trip of
+        src/vectordb.py:216."""
+        if "product_description" not in df.columns:
+            raise ValueError("DataFrame must contain 'product_description' column for embedding.")
+        emb = self.model.embed_device(df["product_description"].tolist())
+        ids = [f"item_{i}" for i in range(len(df))]
+        return ids, emb, self._prepare_metadata(df)
+
+    @property
+    def on_device(self) -> bool:
+        return hasattr(self.model, "embed_device") and str(getattr(self.model, "device", "cpu")).startswith("cuda")
+
     def embed_query(self, query: str) -> np.ndarray:
         return np.array(self.model([query])[0])
 
@@ -163,6 +177,12 @@ class ProductVectorDB:
         if not {"product_description", "product_code"} <= set(unique_products_df.columns):
             raise ValueError("Input DataFrame must contain 'product_description' and 'product_code' columns.")
         unique_products_df["usda_code"] = unique_products_df["product_code"].apply(self._get_usda_code)
+        if getattr(self.embedder, "on_device", False) and getattr(self.collection, "_lib", 0) is None:
+            ids, dev_emb, metadatas = self.embedder.embed_products_device(unique_products_df)
+            for lo in range(0, len(ids), batch_size):
+                self.collection.add(embeddings=dev_emb[lo:lo + batch_size], metadatas=metadatas[lo:lo + batch_size],
+                                    ids=ids[lo:lo + batch_size])
+            return
         ids, embeddings, metadatas = self.embedder.embed_products(unique_products_df)
         for lo in range(0, len(ids), batch_size):
             hi = lo + batch_size
