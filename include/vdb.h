@@ -184,7 +184,8 @@ int vdb_timing_stats(vdb_t* h, int64_t* n_searches, double* scan_ms_sum, double*
 
 /* Tuning knobs: "timing_ring", "timing_every" (record the timing events on every Nth search only; default 1), "scan_blocks_per_cu", "scan_nt_loads", "batch_mfma_min_b" (default 3),
  * "mfma_cost_model" (default 1: a batch takes the MFMA path only where it is faster than ceil(b/4) GEMV passes;
- * 0: whenever it is supported), "mfma_variant", "mfma_append_cap", "mfma_force_fallback".
+ * 0: whenever it is supported), "mfma_variant", "mfma_append_cap", "mfma_split_x1000" (where the sample pass sits between the dense sample and
+ * the full pass; 500 = geometric mean, measured best), "mfma_force_fallback".
  * Unknown names return VDB_ERR_ARG. */
 int vdb_set_option(vdb_t* h, const char* name, int64_t value);
 

@@ -217,7 +217,7 @@ __global__ __launch_bounds__(1024) void select_kth_kernel(const float* __restric
     const bool valid = i < n;
     const float s = valid ? cs[i] : -INFINITY;
     const int id = valid ? (ci ? ci[i] : i) : kIdxSentinel;
-    tk.push_lanes(s, id, valid && s > -INFINITY);
+    tk.push_lanes_bulk(s, id, valid && s > -INFINITY);
   }
   // per-wave lists are sorted: tree-merge with the bitonic wave merge
   {

@@ -60,6 +60,7 @@ struct vdb {
   DevBuf w_cand_s, w_cand_i, w_cand_cnt, w_thr, w_dense, w_list_s, w_list_i;   // append-path state
   DevBuf w_mask;                                                                // host-supplied eligibility bitmap (vdb_search_masked)
   int mfma_append_cap = 16384;   // candidate buffer entries per query
+  int mfma_split_x1000 = 500;    // two append passes: the sample pass covers span^(x/1000) times the dense sample (500 = geometric mean)
   int mfma_variant = 5;          // 3 = barrier ring (scan_mfma3.h), 4 = warp-specialised (scan_mfma4.h),
                                  // 5 = 256x256 tile (scan_mfma5.h) unless it pads the batch > 1.5x further, then 4
   int mfma_last_b = 0;           // batch size of the last MFMA search (locates its overflow flag)
@@ -367,6 +368,7 @@ int mfma_search(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
   for (int pass = 1; pass <= n_pass; ++pass) {
     const bool last = pass == n_pass;
     long long t_next = last ? n_tiles : std::min<long long>(n_tiles, (long long)std::ceil((double)t_cur * growth));
+    if (!last && n_pass == 2) t_next = std::min<long long>(n_tiles, (long long)std::ceil((double)t_cur * std::pow(span, h->mfma_split_x1000 * 1e-3)));
     const int stride = last ? 1 : (int)std::max<long long>(1, n_tiles / t_next);
     HIP_TRY(h, hipMemsetAsync(cand_cnt, 0, (size_t)b * 4, st));
     const MfGrid g = mf_grid(h->n_cu, n_qt, t_next, 1 << 30);
@@ -925,6 +927,10 @@ int vdb_set_option(vdb_t* h, const char* name, int64_t value) {
   if (!strcmp(name, "mfma_variant")) {
     if (value < 3 || value > 5) return fail(h, VDB_ERR_ARG, "mfma_variant must be 3, 4 or 5");
     h->mfma_variant = (int)value; return VDB_OK;
+  }
+  if (!strcmp(name, "mfma_split_x1000")) {
+    if (value < 100 || value > 900) return fail(h, VDB_ERR_ARG, "mfma_split_x1000 must be in [100,900]");
+    h->mfma_split_x1000 = (int)value; return VDB_OK;
   }
   if (!strcmp(name, "mfma_force_fallback")) { h->mfma_force_fallback = value != 0; return VDB_OK; }
   if (!strcmp(name, "mfma_append_cap")) {

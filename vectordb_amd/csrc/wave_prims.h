@@ -108,6 +108,31 @@ struct WaveTopK {
     }
   }
 
+  // Offer one candidate per lane when MANY are expected to qualify (a fresh list, a loose
+  // threshold): more than 8 accepting lanes are sorted in registers (bitonic network, 21
+  // compare-exchange stages, best first) and merged in one bitonic wave merge instead of
+  // being inserted one by one.  Same result as push_lanes.  E == 1 only.
+  __device__ __forceinline__ void push_lanes_bulk(float cs, int ci, bool valid) {
+    static_assert(E == 1, "bitonic wave sort handles one entry per lane");
+    const bool take = valid && accepts(cs, ci);
+    const unsigned long long m = __ballot(take);
+    if (__builtin_popcountll(m) <= 8) { push_lanes(cs, ci, valid); return; }   // wave-uniform
+    const int lane = lane_id();
+    float vs = take ? cs : -INFINITY;
+    int vi = take ? ci : kIdxSentinel;
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1)
+#pragma unroll
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        const float ps = __shfl_xor(vs, j, 64);
+        const int pi = __shfl_xor(vi, j, 64);
+        const bool pb = cand_better(ps, pi, vs, vi);
+        const bool keep_better = ((lane & j) == 0) == ((lane & k) == 0);
+        if (keep_better ? pb : !pb) { vs = ps; vi = pi; }
+      }
+    merge_sorted(vs, vi);
+  }
+
   // Merge another *sorted* (best first) list of <= 64 entries, one per lane
   // (sentinels behind its end), into this one.  Bitonic: lane i keeps the better
   // of own[i] and other[63-i] — the 64 best of the union, as a bitonic sequence —
