@@ -556,3 +556,42 @@ def test_masked_search_other_dims_and_device_entry(hip_lib, oracle_mod):
         torch.cuda.synchronize()
         assert np.array_equal(d_i.cpu().numpy(), idx) and np.array_equal(d_d.cpu().numpy(), dist)
         ix.close()
+
+
+def test_random_shapes_against_oracle(hip_lib, oracle_mod):
+    """Seeded sweep over odd shapes: dims that are not a multiple of the 16-byte chunk, stores smaller
+    than a wave / a tile / k, k up to 300, batches 0..7, both dtypes, with and without rerank, masked or not."""
+    rng = np.random.default_rng(2024)
+    dims = [1, 3, 8, 31, 64, 100, 384, 385, 768, 1000]
+    for case in range(48):
+        dim = dims[case % len(dims)]
+        n = int(rng.choice([1, 2, 7, 63, 64, 65, 200, 513, 1500, 4099]))
+        b = int(rng.integers(0, 8))
+        k = int(rng.choice([1, 2, 10, 33, 64, 65, 128, 300]))
+        dtype = "bf16" if case % 3 == 1 else "f32"
+        kp = 0 if dtype == "f32" or case % 2 else min(1024, max(k, 4 * k))
+        rows = rng.standard_normal((n, dim)).astype(np.float32)
+        if n > 3:
+            rows[3] = rows[1]                                    # a duplicate row: tie broken by index
+        q = rng.standard_normal((b, dim)).astype(np.float32)
+        rows_n = oracle_mod.normalize_rows(rows)
+        src = oracle_mod.round_bf16(rows_n) if (dtype == "bf16" and kp == 0) else rows_n
+        ix = FlatIndex(dim, dtype)
+        ix.add(rows)
+        what = f"case {case}: n={n} dim={dim} b={b} k={k} {dtype} kp={kp}"
+        idx, dist = ix.search(q, k, kp)
+        assert idx.shape == (b, k) and dist.shape == (b, k), what
+        kk = min(k, n)
+        if b:
+            r_idx, r_dist, r_sc = oracle_mod.exact_topk(src, q, kk)
+            assert np.all(idx[:, kk:] == -1) and np.all(np.isinf(dist[:, kk:])), what
+            check_topk(idx[:, :kk], dist[:, :kk], r_idx, r_dist, r_sc, src, _qn(oracle_mod, q), what=what)
+            mask = rng.random(n) < 0.5
+            allowed = np.flatnonzero(mask)
+            mi, md = ix.search_masked(q, k, mask, kp)
+            km = min(k, allowed.size)
+            assert np.all(mi[:, km:] == -1) and np.all(np.isinf(md[:, km:])), what
+            if km:
+                m_idx, m_dist, m_sc = oracle_mod.exact_topk(src[allowed], q, km)
+                check_topk(mi[:, :km], md[:, :km], allowed[m_idx], m_dist, m_sc, src, _qn(oracle_mod, q), what=what + " masked")
+        ix.close()

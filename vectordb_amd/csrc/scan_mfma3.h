@@ -236,38 +236,11 @@ __global__ __launch_bounds__(1024) void select_kth_kernel(const float* __restric
   }
 }
 
-// Dense variant: scores[q][ld], first n columns valid, index = column.
-__global__ __launch_bounds__(1024) void select_kth_dense_kernel(const float* __restrict__ scores, int ld, int n, int kk,
-                                                                float* __restrict__ thr_out) {
-  __shared__ float ls[8 * 64];
-  __shared__ int li[8 * 64];
-  const int q = blockIdx.x;
-  const int w = threadIdx.x >> 6;
-  const int lane = lane_id();
-  const float* cs = scores + (size_t)q * ld;
-  WaveTopK<1> tk;
-  tk.init(kk);
-  for (int base = w * 64; base < n; base += 1024) {
-    const int i = base + lane;
-    const bool valid = i < n;
-    const float s = valid ? cs[i] : -INFINITY;
-    tk.push_lanes(s, valid ? i : kIdxSentinel, valid && s > -INFINITY);
-  }
-#pragma unroll
-  for (int half = 8; half >= 1; half >>= 1) {
-    if (w >= half && w < 2 * half) { ls[(w - half) * 64 + lane] = tk.s[0]; li[(w - half) * 64 + lane] = tk.id[0]; }
-    __syncthreads();
-    if (w < half) tk.merge_sorted(ls[w * 64 + lane], li[w * 64 + lane]);
-    __syncthreads();
-  }
-  if (w == 0 && lane == 0) thr_out[q] = tk.thr_s;
-}
-
 // Cheap valid threshold from the dense sample, one wave per query: lane l takes the maximum of the scores
 // l, l+64, l+128, ...; the kk-th largest of the 64 lane maxima (kk <= 64) is the score of an actual sampled
 // row with at least kk sampled rows at or above it, hence <= the true k'-th best.  A little looser than the
 // exact k'-th best of the sample (1.5 % instead of 1 % of the next pass's scores pass at kk = 40 over 4096
-// rows) but 10x cheaper than select_kth_dense_kernel (127 us at B = 1024).
+// rows) but 10x cheaper than an exact selection over the dense scores (127 us at B = 1024).
 __global__ __launch_bounds__(64) void dense_lower_bound_kernel(const float* __restrict__ scores, int ld, int n, int kk,
                                                                float* __restrict__ thr_out) {
   const int q = blockIdx.x;
