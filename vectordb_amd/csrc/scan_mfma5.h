@@ -90,6 +90,14 @@ __global__ __launch_bounds__(kM5Threads) void scan_mfma_wide_kernel(
     thr[1] = thr_in[min(q0 + 32, b - 1)];
   }
   asm volatile("" :: "v"(thr[0]), "v"(thr[1]));   // retire the loads before the loop (see scan_mfma3.h)
+  // The epilogue's filter runs on the scores' BIT PATTERNS as signed integers: against a positive threshold
+  // (the rule: it is the k'-th best cosine of a sample) "some score >= thr" is "max pattern >= thr's pattern" —
+  // a positive float orders like its pattern, every negative float is a negative integer.  Integer max has no
+  // NaN rule: 10 ops per 16 scores where fmaxf costs 19 (a canonicalising v_max x,x in front of every input).
+  // A lane whose threshold is not positive gets INT_MIN: its filter always fires and the float compare decides.
+  int thr_bits[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) thr_bits[nt] = thr[nt] > 0.f ? __float_as_int(thr[nt]) : (int)0x80000000;
 
   // staging: LDS position L (16-byte units) of an operand image <- row L>>3, global chunk (L&7)^swz;
   // corpus and query tiles have the same shape, so one set of offsets serves both
@@ -296,15 +304,16 @@ __global__ __launch_bounds__(kM5Threads) void scan_mfma_wide_kernel(
             if (qg < b) dense[(size_t)qg * kMf3DenseLd + (tile0 + tile) * kMfBM + rloc] = ok ? acc[mt][nt][reg] : -INFINITY;
           }
         } else {
-          float m4[4];
+          int m4[4];   // bit patterns of the four group maxima
 #pragma unroll
           for (int g = 0; g < 4; ++g)
-            m4[g] = fmaxf(fmaxf(acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1]), fmaxf(acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]));
-          const float m = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
-          if (__ballot(m >= thr[nt]) != 0ull) {
+            m4[g] = max(max(__float_as_int(acc[mt][nt][4 * g]), __float_as_int(acc[mt][nt][4 * g + 1])),
+                        max(__float_as_int(acc[mt][nt][4 * g + 2]), __float_as_int(acc[mt][nt][4 * g + 3])));
+          const int m = max(max(m4[0], m4[1]), max(m4[2], m4[3]));
+          if (__ballot(m >= thr_bits[nt]) != 0ull) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-              if (__ballot(m4[g] >= thr[nt]) == 0ull) continue;
+              if (__ballot(m4[g] >= thr_bits[nt]) == 0ull) continue;
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
                 const float v = acc[mt][nt][4 * g + e];
