@@ -595,3 +595,26 @@ def test_random_shapes_against_oracle(hip_lib, oracle_mod):
                 m_idx, m_dist, m_sc = oracle_mod.exact_topk(src[allowed], q, km)
                 check_topk(mi[:, :km], md[:, :km], allowed[m_idx], m_dist, m_sc, src, _qn(oracle_mod, q), what=what + " masked")
         ix.close()
+
+
+def test_gemv_batches_beyond_one_query_chunk(hip_lib, oracle_mod, corpus20k):
+    """f32 stores (and masked searches) stay on the GEMV scan at any batch size: 150 queries run as
+    three 64-query chunks of 4-query passes; every row equals the oracle and the batch-1 answer."""
+    n, dim, spec, rows, queries = corpus20k
+    rng = np.random.default_rng(5)
+    q = rows[rng.integers(0, n, 150)] + 0.05 * rng.standard_normal((150, dim)).astype(np.float32)
+    ix = FlatIndex(dim, "f32")
+    ix.add_synth(0, n, spec)
+    idx, dist = ix.search(q, 10)
+    r_idx, r_dist, r_sc = oracle_mod.exact_topk(rows, q, 10)
+    check_topk(idx, dist, r_idx, r_dist, r_sc, rows, _qn(oracle_mod, q), what="f32 b=150")
+    for j in (0, 63, 64, 127, 128, 149):
+        i1, d1 = ix.search(q[j:j + 1], 10)
+        assert np.array_equal(i1[0], idx[j]) and np.array_equal(d1[0], dist[j])
+    mask = rng.random(n) < 0.25
+    allowed = np.flatnonzero(mask)
+    mi, md = ix.search_masked(q, 10, mask)
+    m_idx, m_dist, m_sc = oracle_mod.exact_topk(rows[allowed], q, 10)
+    check_topk(mi, md, allowed[m_idx], m_dist, m_sc, rows, _qn(oracle_mod, q), what="f32 masked b=150")
+    assert ix.last_timing()["scan_ms"] > 0
+    ix.close()
