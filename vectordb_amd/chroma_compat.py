@@ -228,15 +228,17 @@ class Collection:
             rows = [idx[i][idx[i] >= 0] for i in range(b)]
             dists = [dist[i][: len(rows[i])] for i in range(b)]
 
-        out: Dict[str, Any] = {"ids": [[self._ids[r] for r in rr] for rr in rows],
+        row_lists = [rr.tolist() for rr in rows]          # plain ints index Python lists ~3x faster than numpy scalars
+        ids_, metas_, docs_ = self._ids, self._metadatas, self._documents
+        out: Dict[str, Any] = {"ids": [[ids_[r] for r in rl] for rl in row_lists],
                                "distances": None, "metadatas": None, "embeddings": None, "documents": None,
                                "uris": None, "data": None, "included": include}
         if "distances" in include:
-            out["distances"] = [[float(d) for d in dd] for dd in dists]
+            out["distances"] = [np.asarray(dd, dtype=np.float64).tolist() for dd in dists]
         if "metadatas" in include:
-            out["metadatas"] = [[self._metadatas[r] for r in rr] for rr in rows]
+            out["metadatas"] = [[metas_[r] for r in rl] for rl in row_lists]
         if "documents" in include:
-            out["documents"] = [[self._documents[r] for r in rr] for rr in rows]
+            out["documents"] = [[docs_[r] for r in rl] for rl in row_lists]
         if "embeddings" in include:
             raw = self._raw_matrix()
             out["embeddings"] = [self._format_embeddings(raw[rr]) for rr in rows]

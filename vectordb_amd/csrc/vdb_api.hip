@@ -58,6 +58,7 @@ struct vdb {
   // workspaces (grown on demand)
   DevBuf w_q, w_part_s, w_part_i, w_part2_s, w_part2_i, w_stage, w_out_i, w_out_d, w_idx, w_mfma;
   DevBuf w_cand_s, w_cand_i, w_cand_cnt, w_thr, w_dense, w_list_s, w_list_i;   // append-path state
+  void* pin = nullptr; size_t pin_bytes = 0;                                     // pinned host staging for small host-pointer searches
   DevBuf w_mask;                                                                // host-supplied eligibility bitmap (vdb_search_masked)
   int mfma_append_cap = 16384;   // candidate buffer entries per query
   int mfma_split_x1000 = 500;    // two append passes: the sample pass covers span^(x/1000) times the dense sample (500 = geometric mean)
@@ -227,6 +228,7 @@ int finish_search(vdb_t* h, int b, int n_parts, int kk, int k, int kp, const flo
   int lists = n_parts;
   if (e == 1) {
     // sorted one-entry-per-lane lists: bitonic folds, 32 lists per block, then one fused finish launch
+    // (letting the finish kernel fold up to 256 lists itself measured slower: 18.9 vs 17.0 us at 231 lists)
     while (lists > 64) {
       const int gx = (lists + 31) / 32;
       hipLaunchKernelGGL(merge_sorted_lists_kernel, dim3(gx, b), dim3(256), 0, st, cur_s, cur_i, lists, 32, kk, oth_s, oth_i);
@@ -588,6 +590,7 @@ void vdb_destroy(vdb_t* h) {
   DevBuf* bufs[] = {&h->w_q, &h->w_part_s, &h->w_part_i, &h->w_part2_s, &h->w_part2_i, &h->w_stage, &h->w_out_i, &h->w_out_d, &h->w_idx, &h->w_mfma,
                     &h->w_cand_s, &h->w_cand_i, &h->w_cand_cnt, &h->w_thr, &h->w_dense, &h->w_list_s, &h->w_list_i, &h->w_mask};
   for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
+  if (h->pin) (void)hipHostFree(h->pin);
   if (h->rows_f32) (void)hipFree(h->rows_f32);
   if (h->rows_bf16) (void)hipFree(h->rows_bf16);
   for (hipEvent_t e : h->ring) if (e) (void)hipEventDestroy(e);
@@ -669,16 +672,42 @@ int vdb_search(vdb_t* h, const float* queries_host, int b, int k, int kp, int64_
   if (rc) return rc;
   if (b == 0) return VDB_OK;
   if ((rc = set_device(h))) return rc;
-  if ((rc = ensure(h, h->w_stage, (size_t)b * h->dim * 4))) return rc;
-  if ((rc = ensure(h, h->w_out_i, (size_t)b * k * 8))) return rc;
-  if ((rc = ensure(h, h->w_out_d, (size_t)b * k * 4))) return rc;
-  HIP_TRY(h, hipMemcpyAsync(h->w_stage.p, queries_host, (size_t)b * h->dim * 4, hipMemcpyHostToDevice, h->stream));
+  const size_t qbytes = (size_t)b * h->dim * 4, ibytes = (size_t)b * k * 8, dbytes = (size_t)b * k * 4;
+  if ((rc = ensure(h, h->w_stage, qbytes))) return rc;
+  if ((rc = ensure(h, h->w_out_i, ibytes + dbytes))) return rc;    // [idx | dist] in one buffer: one copy back
+  int64_t* d_idx = (int64_t*)h->w_out_i.p;
+  float* d_dist = (float*)((char*)h->w_out_i.p + ibytes);
+  // Small calls (every reference call site is batch 1) go through pinned staging: a copy from or to pageable
+  // memory is staged by the runtime and costs ~10 us each at any size; three of them were half of a
+  // 41 us query against a 14 777-row store.
+  const size_t pin_need = qbytes + ibytes + dbytes;
+  const bool pinned = pin_need <= ((size_t)1 << 20);
+  if (pinned && h->pin_bytes < pin_need) {
+    if (h->pin) { HIP_TRY(h, hipStreamSynchronize(h->stream)); HIP_TRY(h, hipHostFree(h->pin)); h->pin = nullptr; h->pin_bytes = 0; }
+    const size_t want = std::max(pin_need, (size_t)65536);
+    HIP_TRY(h, hipHostMalloc(&h->pin, want, hipHostMallocDefault));
+    h->pin_bytes = want;
+  }
+  if (pinned) {
+    memcpy(h->pin, queries_host, qbytes);
+    HIP_TRY(h, hipMemcpyAsync(h->w_stage.p, h->pin, qbytes, hipMemcpyHostToDevice, h->stream));
+  } else {
+    HIP_TRY(h, hipMemcpyAsync(h->w_stage.p, queries_host, qbytes, hipMemcpyHostToDevice, h->stream));
+  }
   float* qn = nullptr;
   if ((rc = prep_queries(h, (const float*)h->w_stage.p, b, h->stream, &qn))) return rc;
-  if ((rc = search_core(h, qn, b, k, kp, -1, (int64_t*)h->w_out_i.p, (float*)h->w_out_d.p, h->stream))) return rc;
-  HIP_TRY(h, hipMemcpyAsync(out_idx, h->w_out_i.p, (size_t)b * k * 8, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(h, hipMemcpyAsync(out_dist, h->w_out_d.p, (size_t)b * k * 4, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if ((rc = search_core(h, qn, b, k, kp, -1, d_idx, d_dist, h->stream))) return rc;
+  if (pinned) {
+    char* back = (char*)h->pin + qbytes;
+    HIP_TRY(h, hipMemcpyAsync(back, h->w_out_i.p, ibytes + dbytes, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    memcpy(out_idx, back, ibytes);
+    memcpy(out_dist, back + ibytes, dbytes);
+  } else {
+    HIP_TRY(h, hipMemcpyAsync(out_idx, d_idx, ibytes, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(out_dist, d_dist, dbytes, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+  }
   return VDB_OK;
 }
 
