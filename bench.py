@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--mfma-min-b", type=int, default=0, help="diagnostic: smallest batch sent to the MFMA path")
     ap.add_argument("--clusters", type=int, default=0, help="synthetic clusters (default sqrt(rows))")
     ap.add_argument("--time-every", type=int, default=4, help="HIP-event timing of the kernel on every Nth step (an event record idles the queue ~6 us)")
+    ap.add_argument("--no-skip-sample", action="store_true", help="diagnostic: the last MFMA pass re-multiplies the sampled tiles")
     ap.add_argument("--mfma-split", type=int, default=0, help="diagnostic: mfma_split_x1000 option")
     ap.add_argument("--ablate", type=int, default=0, help="diagnostic: MFMA kernel ablation bits (results invalid)")
     args = ap.parse_args()
@@ -134,6 +135,8 @@ def main():
         sh.local.set_option("mfma_variant", args.mfma_variant)
     if args.ablate:
         sh.local.set_option("mfma_ablate", args.ablate)
+    if args.no_skip_sample:
+        sh.local.set_option("mfma_skip_sample", 0)
     if args.mfma_split:
         sh.local.set_option("mfma_split_x1000", args.mfma_split)
     if args.mfma_min_b:

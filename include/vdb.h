@@ -191,7 +191,8 @@ int vdb_set_option(vdb_t* h, const char* name, int64_t value);
 
 /* Read-only counters/diagnostics (synchronises the device): "mfma_last_overflow" (1 when the
  * last batched search overflowed its candidate buffers and ran the exact list kernel),
- * "rows", "capacity_rows", "mfma_last_hits"; measured ceilings of this device (a few ms
+ * "rows", "capacity_rows", "mfma_last_hits", "mfma_last_skipped_tiles" (tiles the final pass of the last
+ * batched search left out because the sample pass had multiplied them); measured ceilings of this device (a few ms
  * each): "probe_hbm_read_mbps" (streams the store's own rows, needs >= 64 MiB of them) and
  * "probe_mfma_bf16_gflops" (bare v_mfma_f32_32x32x16_bf16 loop).  Unknown names return VDB_ERR_ARG. */
 int vdb_get_stat(vdb_t* h, const char* name, int64_t* value);

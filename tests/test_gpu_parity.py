@@ -618,3 +618,59 @@ def test_gemv_batches_beyond_one_query_chunk(hip_lib, oracle_mod, corpus20k):
     check_topk(mi, md, allowed[m_idx], m_dist, m_sc, rows, _qn(oracle_mod, q), what="f32 masked b=150")
     assert ix.last_timing()["scan_ms"] > 0
     ix.close()
+
+
+@pytest.mark.parametrize("b", [100, 300])                       # 128-wide (warp-specialised) and 256-wide kernels
+def test_mfma_last_pass_skips_the_sampled_tiles(hip_lib, oracle_mod, corpus20k, b):
+    """Two append passes (forced at 20k rows by a small candidate buffer): the last pass leaves out the tiles
+    the sample pass multiplied and the final selection is seeded with the sample's list.  Exact against the
+    oracle, and identical to the plain form (mfma_skip_sample = 0) that re-multiplies every tile."""
+    n, dim, spec, rows, queries = corpus20k
+    rng = np.random.default_rng(b)
+    q = rows[rng.integers(0, n, b)] + 0.05 * rng.standard_normal((b, dim)).astype(np.float32)
+    ix = FlatIndex(dim, "bf16", True)
+    ix.add_synth(0, n, spec)
+    ix.set_option("mfma_cost_model", 0)
+    ix.set_option("mfma_append_cap", 512)                      # R = 512/(4*40) = 3.2 -> dense sample, 36-tile sample at stride 2, rest
+    out = {}
+    for skip in (1, 0):
+        ix.set_option("mfma_skip_sample", skip)
+        out[skip] = ix.search(q, 10, 40)
+        assert ix.get_stat("mfma_last_overflow") == 0 and ix.get_stat("mfma_last_hits") > 0
+        assert ix.get_stat("mfma_last_skipped_tiles") == (36 if skip else 0)          # ceil(16 * sqrt(79/16)) sampled tiles
+    assert np.array_equal(out[1][0], out[0][0]) and np.array_equal(out[1][1], out[0][1])
+    r_idx, r_dist, r_sc = oracle_mod.exact_topk(rows, q, 10)
+    swaps = check_topk(out[1][0], out[1][1], r_idx, r_dist, r_sc, rows, _qn(oracle_mod, q), what=f"skip-sample b={b}")
+    assert recall_at_k(out[1][0], r_idx) >= 1.0 - swaps / out[1][0].size - 1e-12
+    # self-join form (the excluded row may sit in a sampled tile or in the rest)
+    sj1 = ix.selfjoin(5, exclude_self=True, rerank_kprime=40, q_row0=1000, q_n=b)
+    ix.set_option("mfma_skip_sample", 1)
+    sj2 = ix.selfjoin(5, exclude_self=True, rerank_kprime=40, q_row0=1000, q_n=b)
+    assert np.array_equal(sj1[0], sj2[0]) and not np.any(sj2[0] == (1000 + np.arange(b))[:, None])
+    ix.close()
+
+
+def test_mfma_two_passes_at_a_million_rows_equal_the_gemv_scan(hip_lib):
+    """Default candidate buffer, 1M rows (3 907 tiles: dense sample, strided sample pass, rest): the batched
+    path returns bit for bit what the GEMV scan returns after the fp32 rerank."""
+    n, dim = 1_000_000, 768
+    spec = SynthSpec(seed=77, kind=1, n_clusters=1000, noise=0.3)
+    qspec = SynthSpec(seed=78, kind=2, noise=0.5, base_kind=1, base_seed=77, base_n=n, base_n_clusters=1000, base_noise=0.3)
+    import torch
+    ix = FlatIndex(dim, "bf16", True)
+    ix.add_synth(0, n, spec)
+    qd = torch.empty((300, dim), dtype=torch.float32, device="cuda")
+    ix.synth_rows_device(qd.data_ptr(), 0, 300, qspec, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    q = qd.cpu().numpy()
+    ix.set_option("mfma_cost_model", 0)
+    res = {}
+    for b in (64, 300):
+        res[b] = ix.search(q[:b], 10, 40)
+        assert ix.get_stat("mfma_last_hits") > 0 and ix.get_stat("mfma_last_overflow") == 0
+        assert ix.get_stat("mfma_last_skipped_tiles") > 100
+    ix.set_option("batch_mfma_min_b", 1 << 20)                  # everything on the GEMV scan
+    gi, gd = ix.search(q, 10, 40)
+    for b in (64, 300):
+        assert np.array_equal(res[b][0], gi[:b]) and np.array_equal(res[b][1], gd[:b])
+    ix.close()

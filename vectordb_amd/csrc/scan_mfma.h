@@ -64,6 +64,22 @@ __global__ void queries_to_bf16_kernel(const float* __restrict__ qn, int b, int 
   }
 }
 
+// Which corpus tile is pass-local tile i?
+//   skip_n == 0 : i * stride — a strided sample (stride > 1) or every tile (stride 1).
+//   skip_n  > 0 : the tiles the sample {0, stride, ..., (skip_n-1)*stride} left out, ascending (stride >= 2):
+//                 the last pass then neither re-multiplies the sampled tiles nor loses their candidates
+//                 (select_kth_kernel is seeded with the sample's sorted list).
+__device__ __forceinline__ int pass_tile(int i, int stride, int skip_n) {
+  if (skip_n == 0) return i * stride;
+  const int per = stride - 1, first = skip_n * per;
+  return i < first ? (i / per) * stride + 1 + i % per : skip_n * stride + (i - first);
+}
+__device__ __forceinline__ int pass_tile_next(int g, int stride, int skip_n) {
+  if (skip_n == 0) return g + stride;
+  const int n = g + 1;
+  return (n % stride == 0 && n / stride < skip_n) ? n + 1 : n;
+}
+
 __device__ __forceinline__ void mf_glds16(const unsigned char* gptr, unsigned char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);

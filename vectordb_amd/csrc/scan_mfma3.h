@@ -192,11 +192,14 @@ __global__ __launch_bounds__(kMfThreads) void scan_mfma_pass_kernel(
 
 // Per query: the k'-th best of its candidates -> thr_out[q]; optionally the sorted top-k'
 // list -> list_*[q][kk].  Candidates: dense scores (cand_i == nullptr, index = position) or
-// an append buffer with cand_cnt[q] entries (capacity cap; more -> *overflow = 1).
+// an append buffer with cand_cnt[q] entries (capacity cap; more -> *overflow = 1), optionally merged with a
+// seed list (seed_*).
 __global__ __launch_bounds__(1024) void select_kth_kernel(const float* __restrict__ cand_s, const int* __restrict__ cand_i,
                                                           const int* __restrict__ cand_cnt, int cap_or_n, int kk,
                                                           float* __restrict__ thr_out, float* __restrict__ list_s,
-                                                          int* __restrict__ list_i, int* __restrict__ overflow) {
+                                                          int* __restrict__ list_i, int* __restrict__ overflow,
+                                                          const float* __restrict__ seed_s = nullptr,
+                                                          const int* __restrict__ seed_i = nullptr) {
   __shared__ float ls[8 * 64];
   __shared__ int li[8 * 64];
   const int q = blockIdx.x;
@@ -231,6 +234,9 @@ __global__ __launch_bounds__(1024) void select_kth_kernel(const float* __restric
     }
   }
   if (w == 0) {
+    // seed: a sorted list of kk entries per query from an earlier pass over OTHER rows (the sample's tiles
+    // when the last pass skips them); -inf / sentinel entries behind its end
+    if (seed_s) tk.merge_sorted(lane < kk ? seed_s[(size_t)q * kk + lane] : -INFINITY, lane < kk ? seed_i[(size_t)q * kk + lane] : kIdxSentinel);
     if (lane == 0) thr_out[q] = tk.thr_s;
     if (list_s) tk.store(list_s + (size_t)q * kk, list_i + (size_t)q * kk);
   }

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(kWsThreads) void scan_mfma_ws_kernel(
     const unsigned char* __restrict__ rows, int n_rows, const unsigned char* __restrict__ qb16, int b, int n_qtiles,
     int n_splits, int tiles_per_split, int n_pass_tiles, int tile_stride, int self0, int xcd_map,
     const float* __restrict__ thr_in, float* __restrict__ dense, int* __restrict__ cand_cnt,
-    float* __restrict__ cand_s, int* __restrict__ cand_i, int cap, int* __restrict__ fail_flag, int ablate) {
+    float* __restrict__ cand_s, int* __restrict__ cand_i, int cap, int* __restrict__ fail_flag, int ablate, int skip_n) {
   extern __shared__ __align__(16) unsigned char smem[];   // 3 stages + 64 B of counters (one LDS object)
   int* ctr = reinterpret_cast<int*>(smem + kMfNumStages * kMfStage);   // [0..2] FULL, [4..6] FREE
   const int tid = threadIdx.x;
@@ -95,8 +95,9 @@ __global__ __launch_bounds__(kWsThreads) void scan_mfma_ws_kernel(
     const unsigned lane_off = (unsigned)(lrow * kMfRowBytes + (((lane & 7) ^ ((4 * p + (lane >> 4)) & 7)) << 4));
     const unsigned char* qblk = qb16 + (size_t)qbase * kMfRowBytes;
     int is_tile = 0, is_ks = 0, is_slot = 0, is_round = 0, issued = 0;   // cursor of the next stage to issue
+    int is_g = pass_tile(tile0, tile_stride, skip_n);                    // its corpus tile (scan_mfma.h)
     auto issue_next = [&]() {
-      const unsigned char* abase = rows + (size_t)(tile0 + is_tile) * tile_stride * (kMfBM * kMfRowBytes) + is_ks * (kMfBK * 2);
+      const unsigned char* abase = rows + (size_t)is_g * (kMfBM * kMfRowBytes) + is_ks * (kMfBK * 2);
       const unsigned char* bbase = qblk + is_ks * (kMfBK * 2);
       unsigned char* st = smem + is_slot * kMfStage + p * 1024;
       if (!(ablate & 1)) {   // ablate bit 0: diagnostic timing runs without the loads (results invalid)
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(kWsThreads) void scan_mfma_ws_kernel(
         for (int i = 0; i < 4; ++i) mf_glds16(bbase + (size_t)i * (32 * kMfRowBytes) + lane_off, st + kMfStageA + i * 4096);
       }
       ++issued;
-      if (++is_ks == kMfSteps) { is_ks = 0; ++is_tile; }
+      if (++is_ks == kMfSteps) { is_ks = 0; ++is_tile; is_g = pass_tile_next(is_g, tile_stride, skip_n); }
       if (++is_slot == kMfNumStages) { is_slot = 0; ++is_round; }
     };
     issue_next();
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(kWsThreads) void scan_mfma_ws_kernel(
     if (ablate & 4) { ++tile; continue; }   // ablate bit 2: no epilogue
 
     // ---------------- epilogue of pass-local tile (tile0 + tile): identical to scan_mfma3.h ----------------
-    const long long tile_row0 = (long long)(tile0 + tile) * tile_stride * kMfBM;
+    const long long tile_row0 = (long long)pass_tile(tile0 + tile, tile_stride, skip_n) * kMfBM;
     const bool needs_mask = (tile_row0 + kMfBM > n_rows) || (qbase + kMfBN > b) || (self0 >= 0);
 #pragma unroll
     for (int idx = 0; idx < 64; ++idx) {

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(kM5Threads) void scan_mfma_wide_kernel(
     const unsigned char* __restrict__ rows, int n_rows, const unsigned char* __restrict__ qb16, int b, int n_qtiles,
     int n_splits, int tiles_per_split, int n_pass_tiles, int tile_stride, int self0, int xcd_map,
     const float* __restrict__ thr_in, float* __restrict__ dense, int* __restrict__ cand_cnt,
-    float* __restrict__ cand_s, int* __restrict__ cand_i, int cap, int ablate) {
+    float* __restrict__ cand_s, int* __restrict__ cand_i, int cap, int ablate, int skip_n) {
   extern __shared__ __align__(16) unsigned char smem[];   // the only LDS object: 3 corpus + 2 query slots
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -109,10 +109,11 @@ __global__ __launch_bounds__(kM5Threads) void scan_mfma_wide_kernel(
   }
   const int wbase16 = w * 1024;
   const unsigned char* qblk = qb16 + (size_t)qbase * kMfRowBytes;
-  const size_t tile_bytes = (size_t)tile_stride * (kMfBM * kMfRowBytes);
-  const unsigned char* ta = rows + (size_t)tile0 * tile_bytes;   // corpus tile being multiplied
-  const unsigned char* tn = my_tiles > 1 ? ta + tile_bytes : ta; // the one after it (the last tile names itself:
-                                                                 // its trailing stage loads land in slots nobody reads)
+  constexpr size_t kTileBytes = (size_t)kMfBM * kMfRowBytes;
+  int g_cur = pass_tile(tile0, tile_stride, skip_n);             // corpus tile being multiplied (scan_mfma.h)
+  int g_nxt = my_tiles > 1 ? pass_tile_next(g_cur, tile_stride, skip_n) : g_cur;   // the one after it (the last tile names
+  const unsigned char* ta = rows + (size_t)g_cur * kTileBytes;                     // itself: its trailing stage loads land
+  const unsigned char* tn = rows + (size_t)g_nxt * kTileBytes;                     // in slots nobody reads)
   // This wave's four 1 KiB pieces of a stage.  s_abs = K-step index counted from the current
   // tile's first (12..14 = the next tile's first three).
   auto stage_a = [&](int slot, int s_abs, int i0, int i1) {
@@ -282,12 +283,13 @@ __global__ __launch_bounds__(kM5Threads) void scan_mfma_wide_kernel(
     step(I0{}, I1{}, I0{}, 9);
     step(I1{}, I0{}, I0{}, 10);
     step(I2{}, I1{}, I0{}, 11);
+    const long long tile_row0 = (long long)g_cur * kMfBM;
     ta = tn;
-    if (tile + 2 < my_tiles) tn += tile_bytes;
+    g_cur = g_nxt;
+    if (tile + 2 < my_tiles) { g_nxt = pass_tile_next(g_nxt, tile_stride, skip_n); tn = rows + (size_t)g_nxt * kTileBytes; }
     if (ablate & 4) continue;   // ablate bit 2: no epilogue (diagnostic, results invalid)
 
     // ---------------- epilogue of pass-local tile (tile0 + tile) ----------------
-    const long long tile_row0 = (long long)(tile0 + tile) * tile_stride * kMfBM;
     const bool needs_mask = (tile_row0 + kMfBM > n_rows) || (qbase + kM5BN > b) || (self0 >= 0);
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {

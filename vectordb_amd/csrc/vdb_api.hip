@@ -58,6 +58,8 @@ struct vdb {
   // workspaces (grown on demand)
   DevBuf w_q, w_part_s, w_part_i, w_part2_s, w_part2_i, w_stage, w_out_i, w_out_d, w_idx, w_mfma;
   DevBuf w_cand_s, w_cand_i, w_cand_cnt, w_thr, w_dense, w_list_s, w_list_i;   // append-path state
+  DevBuf w_seed_s, w_seed_i;      // the sample pass's sorted list (seeds the final selection)
+  int mfma_skip_sample = 1;       // 1: the last of two passes leaves out the sample pass's tiles
   void* pin = nullptr; size_t pin_bytes = 0;                                     // pinned host staging for small host-pointer searches
   DevBuf w_mask;                                                                // host-supplied eligibility bitmap (vdb_search_masked)
   int mfma_append_cap = 16384;   // candidate buffer entries per query
@@ -65,6 +67,7 @@ struct vdb {
   int mfma_variant = 5;          // 3 = barrier ring (scan_mfma3.h), 4 = warp-specialised (scan_mfma4.h),
                                  // 5 = 256x256 tile (scan_mfma5.h) unless it pads the batch > 1.5x further, then 4
   int mfma_last_b = 0;           // batch size of the last MFMA search (locates its overflow flag)
+  int mfma_last_skipped = 0;     // tiles the last MFMA search's final pass left out (the sample pass's)
   int mfma_force_fallback = 0;   // test hook: route through the exact list kernel
   std::string err;
 };
@@ -303,6 +306,8 @@ int mfma_search(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
   if ((rc = ensure(h, h->w_dense, (size_t)b * kMf3DenseLd * 4))) return rc;
   if ((rc = ensure(h, h->w_list_s, (size_t)b * kk * 4))) return rc;
   if ((rc = ensure(h, h->w_list_i, (size_t)b * kk * 4))) return rc;
+  if ((rc = ensure(h, h->w_seed_s, (size_t)b * kk * 4))) return rc;
+  if ((rc = ensure(h, h->w_seed_i, (size_t)b * kk * 4))) return rc;
   const MfGrid fb = mf_grid(h->n_cu, n_qt_fb, n_tiles, 64);   // fallback grid (<= 64 partial lists per query)
   const size_t part_elems = (size_t)b * fb.n_splits * kk;
   if ((rc = ensure(h, h->w_part_s, part_elems * 4))) return rc;
@@ -326,10 +331,13 @@ int mfma_search(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
   int* cand_cnt = (int*)h->w_cand_cnt.p;
   int* ovf = cand_cnt + b;
   h->mfma_last_b = b;
+  h->mfma_last_skipped = 0;
   float* thr = (float*)h->w_thr.p;
   float* dense = (float*)h->w_dense.p;
   float* list_s = (float*)h->w_list_s.p;
   int* list_i = (int*)h->w_list_i.p;
+  float* seed_s = (float*)h->w_seed_s.p;
+  int* seed_i = (int*)h->w_seed_i.p;
   const size_t smem3 = (size_t)kMfNumStages * kMfStage;
 
   hipLaunchKernelGGL(queries_to_bf16_kernel, dim3(std::min(1024, (b_pad * kMfDim + 255) / 256)), dim3(256), 0, st,
@@ -346,11 +354,11 @@ int mfma_search(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
     if (variant == 5)
       hipLaunchKernelGGL((scan_mfma_wide_kernel<0>), dim3(n_qt * g.n_splits), dim3(kM5Threads), m5_smem_bytes(), st, rows, n_rows, qb16, b,
                          n_qt, g.n_splits, g.tiles_per_split, (int)t_cur, stride, self0, g.xcd_map, (const float*)nullptr, dense,
-                         (int*)nullptr, (float*)nullptr, (int*)nullptr, 0, 0);
+                         (int*)nullptr, (float*)nullptr, (int*)nullptr, 0, 0, 0);
     else if (variant == 4)
       hipLaunchKernelGGL((scan_mfma_ws_kernel<0>), dim3(n_qt * g.n_splits), dim3(kWsThreads), ws_smem_bytes(), st, rows, n_rows, qb16, b,
                          n_qt, g.n_splits, g.tiles_per_split, (int)t_cur, stride, self0, g.xcd_map, (const float*)nullptr, dense,
-                         (int*)nullptr, (float*)nullptr, (int*)nullptr, 0, ovf, 0);
+                         (int*)nullptr, (float*)nullptr, (int*)nullptr, 0, ovf, 0, 0);
     else
       hipLaunchKernelGGL((scan_mfma_pass_kernel<0>), dim3(n_qt * g.n_splits), dim3(kMfThreads), smem3, st, rows, n_rows, qb16, b,
                          n_qt, g.n_splits, g.tiles_per_split, (int)t_cur, stride, self0, g.xcd_map, (const float*)nullptr, dense,
@@ -367,32 +375,48 @@ int mfma_search(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
   const double span = (double)n_tiles / (double)t_cur;
   const int n_pass = span <= 1.0 ? 1 : std::max(1, (int)std::ceil(std::log(span) / std::log(Rmax) - 0.15));   // up to ~2x Rmax per pass
   const double growth = std::pow(span, 1.0 / n_pass);
+  // Two passes (the usual case): the last one leaves out the tiles the sample pass multiplied and the final
+  // selection is seeded with the sample's sorted list instead — the sample is 2 % of the tiles at 10M rows,
+  // 6 % at an 8-GPU shard's 1.25M.  (Not with the barrier-ring kernel, variant 3, which keeps plain indexing.)
+  bool seeded = false;
+  int seed_stride = 0, seed_n = 0;   // the sample the seed list came from: tiles 0, stride, ..., (n-1)*stride
   for (int pass = 1; pass <= n_pass; ++pass) {
     const bool last = pass == n_pass;
     long long t_next = last ? n_tiles : std::min<long long>(n_tiles, (long long)std::ceil((double)t_cur * growth));
     if (!last && n_pass == 2) t_next = std::min<long long>(n_tiles, (long long)std::ceil((double)t_cur * std::pow(span, h->mfma_split_x1000 * 1e-3)));
-    const int stride = last ? 1 : (int)std::max<long long>(1, n_tiles / t_next);
+    int stride = last ? 1 : (int)std::max<long long>(1, n_tiles / t_next);
+    int skip_n = 0;
+    long long pass_tiles = t_next;
+    if (last && seeded) { stride = seed_stride; skip_n = seed_n; pass_tiles = n_tiles - skip_n; h->mfma_last_skipped = skip_n; }
     HIP_TRY(h, hipMemsetAsync(cand_cnt, 0, (size_t)b * 4, st));
-    const MfGrid g = mf_grid(h->n_cu, n_qt, t_next, 1 << 30);
-    if (variant == 5) {
-      auto kern = (h->mfma_ablate & 8) ? scan_mfma_wide_kernel<1, 3> : (h->mfma_ablate & 1) ? scan_mfma_wide_kernel<1, 1> : (h->mfma_ablate & 2) ? scan_mfma_wide_kernel<1, 2> : scan_mfma_wide_kernel<1, 0>;
-      hipLaunchKernelGGL(kern, dim3(n_qt * g.n_splits), dim3(kM5Threads), m5_smem_bytes(), st, rows, n_rows, qb16, b,
-                         n_qt, g.n_splits, g.tiles_per_split, (int)t_next, stride, self0, g.xcd_map, (const float*)thr, dense,
-                         cand_cnt, cand_s, cand_i, cap, h->mfma_ablate);
+    if (pass_tiles > 0) {
+      const MfGrid g = mf_grid(h->n_cu, n_qt, pass_tiles, 1 << 30);
+      if (variant == 5) {
+        auto kern = (h->mfma_ablate & 8) ? scan_mfma_wide_kernel<1, 3> : (h->mfma_ablate & 1) ? scan_mfma_wide_kernel<1, 1> : (h->mfma_ablate & 2) ? scan_mfma_wide_kernel<1, 2> : scan_mfma_wide_kernel<1, 0>;
+        hipLaunchKernelGGL(kern, dim3(n_qt * g.n_splits), dim3(kM5Threads), m5_smem_bytes(), st, rows, n_rows, qb16, b,
+                           n_qt, g.n_splits, g.tiles_per_split, (int)pass_tiles, stride, self0, g.xcd_map, (const float*)thr, dense,
+                           cand_cnt, cand_s, cand_i, cap, h->mfma_ablate, skip_n);
+      }
+      else if (variant == 4)
+        hipLaunchKernelGGL((scan_mfma_ws_kernel<1>), dim3(n_qt * g.n_splits), dim3(kWsThreads), ws_smem_bytes(), st, rows, n_rows, qb16, b,
+                           n_qt, g.n_splits, g.tiles_per_split, (int)pass_tiles, stride, self0, g.xcd_map, (const float*)thr, dense,
+                           cand_cnt, cand_s, cand_i, cap, ovf, h->mfma_ablate, skip_n);
+      else
+        hipLaunchKernelGGL((scan_mfma_pass_kernel<1>), dim3(n_qt * g.n_splits), dim3(kMfThreads), smem3, st, rows, n_rows, qb16, b,
+                           n_qt, g.n_splits, g.tiles_per_split, (int)pass_tiles, stride, self0, g.xcd_map, (const float*)thr, dense,
+                           cand_cnt, cand_s, cand_i, cap);
+      HIP_TRY(h, hipGetLastError());
     }
-    else if (variant == 4)
-      hipLaunchKernelGGL((scan_mfma_ws_kernel<1>), dim3(n_qt * g.n_splits), dim3(kWsThreads), ws_smem_bytes(), st, rows, n_rows, qb16, b,
-                         n_qt, g.n_splits, g.tiles_per_split, (int)t_next, stride, self0, g.xcd_map, (const float*)thr, dense,
-                         cand_cnt, cand_s, cand_i, cap, ovf, h->mfma_ablate);
-    else
-      hipLaunchKernelGGL((scan_mfma_pass_kernel<1>), dim3(n_qt * g.n_splits), dim3(kMfThreads), smem3, st, rows, n_rows, qb16, b,
-                         n_qt, g.n_splits, g.tiles_per_split, (int)t_next, stride, self0, g.xcd_map, (const float*)thr, dense,
-                         cand_cnt, cand_s, cand_i, cap);
-    HIP_TRY(h, hipGetLastError());
     if (last) h->last_bytes = (double)n_rows * kMfDim * 2;
+    // the sample pass of a two-pass search keeps its sorted list when the last pass can leave its tiles out
+    const bool keep = !last && n_pass == 2 && variant != 3 && stride >= 2 && h->mfma_skip_sample;
     hipLaunchKernelGGL(select_kth_kernel, dim3(b), dim3(1024), 0, st, (const float*)cand_s, (const int*)cand_i,
-                       (const int*)cand_cnt, cap, kk, thr, last ? list_s : (float*)nullptr, last ? list_i : (int*)nullptr, ovf);
+                       (const int*)cand_cnt, cap, kk, thr, (last || keep) ? (last ? list_s : seed_s) : (float*)nullptr,
+                       (last || keep) ? (last ? list_i : seed_i) : (int*)nullptr, ovf,
+                       (last && seeded) ? (const float*)seed_s : (const float*)nullptr,
+                       (last && seeded) ? (const int*)seed_i : (const int*)nullptr);
     HIP_TRY(h, hipGetLastError());
+    if (keep) { seeded = true; seed_stride = stride; seed_n = (int)t_next; }
     t_cur = t_next;
   }
   if (h->mfma_force_fallback) HIP_TRY(h, hipMemsetAsync(ovf, 1, 1, st));
@@ -588,7 +612,7 @@ void vdb_destroy(vdb_t* h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   DevBuf* bufs[] = {&h->w_q, &h->w_part_s, &h->w_part_i, &h->w_part2_s, &h->w_part2_i, &h->w_stage, &h->w_out_i, &h->w_out_d, &h->w_idx, &h->w_mfma,
-                    &h->w_cand_s, &h->w_cand_i, &h->w_cand_cnt, &h->w_thr, &h->w_dense, &h->w_list_s, &h->w_list_i, &h->w_mask};
+                    &h->w_cand_s, &h->w_cand_i, &h->w_cand_cnt, &h->w_thr, &h->w_dense, &h->w_list_s, &h->w_list_i, &h->w_mask, &h->w_seed_s, &h->w_seed_i};
   for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
   if (h->pin) (void)hipHostFree(h->pin);
   if (h->rows_f32) (void)hipFree(h->rows_f32);
@@ -961,6 +985,7 @@ int vdb_set_option(vdb_t* h, const char* name, int64_t value) {
     if (value < 100 || value > 900) return fail(h, VDB_ERR_ARG, "mfma_split_x1000 must be in [100,900]");
     h->mfma_split_x1000 = (int)value; return VDB_OK;
   }
+  if (!strcmp(name, "mfma_skip_sample")) { h->mfma_skip_sample = value != 0; return VDB_OK; }
   if (!strcmp(name, "mfma_force_fallback")) { h->mfma_force_fallback = value != 0; return VDB_OK; }
   if (!strcmp(name, "mfma_append_cap")) {
     if (value < 256 || value > (1 << 22)) return fail(h, VDB_ERR_ARG, "mfma_append_cap must be in [256, 4194304]");
@@ -1035,6 +1060,7 @@ int vdb_get_stat(vdb_t* h, const char* name, int64_t* value) {
     *value = (int64_t)best;
     return VDB_OK;
   }
+  if (!strcmp(name, "mfma_last_skipped_tiles")) { *value = h->mfma_last_skipped; return VDB_OK; }
   if (!strcmp(name, "mfma_last_hits")) {   // candidates appended by the last (full) pass, summed over queries
     *value = 0;
     if (!h->w_cand_cnt.p || h->mfma_last_b <= 0) return VDB_OK;
