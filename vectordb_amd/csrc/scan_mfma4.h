@@ -142,6 +142,11 @@ __global__ __launch_bounds__(kWsThreads) void scan_mfma_ws_kernel(
     thr[1] = thr_in[min(q0 + 32, b - 1)];
   }
   asm volatile("" :: "v"(thr[0]), "v"(thr[1]));   // retire the loads before the loop
+  // block filter of the epilogue on the scores' bit patterns (see scan_mfma5.h): exact against a positive
+  // threshold; a lane with a non-positive one gets INT_MIN, its filter always fires
+  int thr_bits[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) thr_bits[nt] = thr[nt] > 0.f ? __float_as_int(thr[nt]) : (int)0x80000000;
   const int ar0 = wm * 64 + (lane & 31), ar1 = ar0 + 32;
   const int br0 = wn * 64 + (lane & 31), br1 = br0 + 32;
   int fa0[4], fa1[4], fb0[4], fb1[4];
@@ -195,27 +200,36 @@ __global__ __launch_bounds__(kWsThreads) void scan_mfma_ws_kernel(
     ks = 0;
     if (ablate & 4) { ++tile; continue; }   // ablate bit 2: no epilogue
 
-    // ---------------- epilogue of pass-local tile (tile0 + tile): identical to scan_mfma3.h ----------------
+    // ---------------- epilogue of pass-local tile (tile0 + tile) ----------------
     const long long tile_row0 = (long long)pass_tile(tile0 + tile, tile_stride, skip_n) * kMfBM;
     const bool needs_mask = (tile_row0 + kMfBM > n_rows) || (qbase + kMfBN > b) || (self0 >= 0);
 #pragma unroll
-    for (int idx = 0; idx < 64; ++idx) {
-      const int mt = idx >> 5, nt = (idx >> 4) & 1, reg = idx & 15;
-      const float v = acc[mt][nt][reg];
-      const int rloc = wm * 64 + mt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hsel;
-      const int qg = qbase + wn * 64 + nt * 32 + (lane & 31);
-      if (MODE == 0) {
-        const int row = (int)tile_row0 + rloc;
-        const bool okr = (row < n_rows) && !(self0 >= 0 && row == self0 + qg);
-        if (qg < b) dense[(size_t)qg * kMf3DenseLd + (tile0 + tile) * kMfBM + rloc] = okr ? v : -INFINITY;
-      } else {
-        bool pass = v >= thr[nt];
-        if (__ballot(pass) == 0ull) continue;
-        const int row = (int)tile_row0 + rloc;
-        if (needs_mask) pass = pass && (row < n_rows) && (qg < b) && !(self0 >= 0 && row == self0 + qg);
-        if (pass) {
-          const int pos = atomicAdd(&cand_cnt[qg], 1);
-          if (pos < cap) { cand_s[(size_t)qg * cap + pos] = v; cand_i[(size_t)qg * cap + pos] = row; }
+    for (int blk = 0; blk < 4; ++blk) {
+      const int mt = blk >> 1, nt = blk & 1;
+      if (MODE == 1) {   // one integer max tree + one ballot per 32x32 block; hits are ~1e-4 of the scores
+        int m = __float_as_int(acc[mt][nt][0]);
+#pragma unroll
+        for (int reg = 1; reg < 16; ++reg) m = max(m, __float_as_int(acc[mt][nt][reg]));
+        if (__ballot(m >= thr_bits[nt]) == 0ull) continue;
+      }
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const float v = acc[mt][nt][reg];
+        const int rloc = wm * 64 + mt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hsel;
+        const int qg = qbase + wn * 64 + nt * 32 + (lane & 31);
+        if (MODE == 0) {
+          const int row = (int)tile_row0 + rloc;
+          const bool okr = (row < n_rows) && !(self0 >= 0 && row == self0 + qg);
+          if (qg < b) dense[(size_t)qg * kMf3DenseLd + (tile0 + tile) * kMfBM + rloc] = okr ? v : -INFINITY;
+        } else {
+          bool pass = v >= thr[nt];
+          if (__ballot(pass) == 0ull) continue;
+          const int row = (int)tile_row0 + rloc;
+          if (needs_mask) pass = pass && (row < n_rows) && (qg < b) && !(self0 >= 0 && row == self0 + qg);
+          if (pass) {
+            const int pos = atomicAdd(&cand_cnt[qg], 1);
+            if (pos < cap) { cand_s[(size_t)qg * cap + pos] = v; cand_i[(size_t)qg * cap + pos] = row; }
+          }
         }
       }
     }
