@@ -94,7 +94,7 @@ __global__ __launch_bounds__(kWsThreads) void scan_mfma_ws_kernel(
     const int lrow = 8 * p + (lane >> 3);
     const unsigned lane_off = (unsigned)(lrow * kMfRowBytes + (((lane & 7) ^ ((4 * p + (lane >> 4)) & 7)) << 4));
     const unsigned char* qblk = qb16 + (size_t)qbase * kMfRowBytes;
-    int is_tile = 0, is_ks = 0, is_slot = 0, is_round = 0, issued = 0;   // cursor of the next stage to issue
+    int is_ks = 0, is_slot = 0, is_round = 0, issued = 0;   // cursor of the next stage to issue
     int is_g = pass_tile(tile0, tile_stride, skip_n);                    // its corpus tile (scan_mfma.h)
     auto issue_next = [&]() {
       const unsigned char* abase = rows + (size_t)is_g * (kMfBM * kMfRowBytes) + is_ks * (kMfBK * 2);
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(kWsThreads) void scan_mfma_ws_kernel(
         for (int i = 0; i < 4; ++i) mf_glds16(bbase + (size_t)i * (32 * kMfRowBytes) + lane_off, st + kMfStageA + i * 4096);
       }
       ++issued;
-      if (++is_ks == kMfSteps) { is_ks = 0; ++is_tile; is_g = pass_tile_next(is_g, tile_stride, skip_n); }
+      if (++is_ks == kMfSteps) { is_ks = 0; is_g = pass_tile_next(is_g, tile_stride, skip_n); }
       if (++is_slot == kMfNumStages) { is_slot = 0; ++is_round; }
     };
     issue_next();

@@ -210,7 +210,6 @@ __global__ __launch_bounds__(kM5Threads) void scan_mfma_wide_kernel(
     pend_n = 0;
   };
   unsigned long long prof_a = 0, prof_b = 0, prof_c = 0, prof_d = 0, prof_last = 0;
-  int prof_n = 0;
   // one K-step on corpus slot AS and query slot BS (compile-time); ks is a scalar
   auto step = [&](auto as_tag, auto bs_tag, auto first_tag, int ks) {
     // keep ks opaque: as a literal it is folded into forty-odd per-lane 64-bit source offsets that spill
@@ -252,7 +251,6 @@ __global__ __launch_bounds__(kM5Threads) void scan_mfma_wide_kernel(
       prof_a += t2 - t1;
       prof_b += t3 - t2;
       prof_last = t3;
-      ++prof_n;
     }
     stage_b(BS, ks + 2, 0, 4);                // the query slot just released
     if (ABL == 3) {
