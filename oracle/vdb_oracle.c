@@ -213,7 +213,7 @@ static int fail(vdb_t* h, int code, const char* msg) {
 int vdb_create(vdb_t** out, int dim, int dtype, int keep_f32, int device_id) {
   (void)device_id;
   if (!out) return fail(NULL, VDB_ERR_ARG, "vdb_create: out is NULL");
-  if (dim <= 0 || dim > 65536) return fail(NULL, VDB_ERR_ARG, "vdb_create: dim must be in [1,65536]");
+  if (dim <= 0 || dim > 32768) return fail(NULL, VDB_ERR_ARG, "vdb_create: dim must be in [1,32768]");
   if (dtype != VDB_F32 && dtype != VDB_BF16) return fail(NULL, VDB_ERR_ARG, "vdb_create: dtype must be 0 (f32) or 1 (bf16)");
   vdb_t* h = (vdb_t*)calloc(1, sizeof(vdb_t));
   if (!h) return fail(NULL, VDB_ERR_MEMORY, "vdb_create: out of memory");

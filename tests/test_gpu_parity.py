@@ -674,3 +674,23 @@ def test_mfma_two_passes_at_a_million_rows_equal_the_gemv_scan(hip_lib):
     for b in (64, 300):
         assert np.array_equal(res[b][0], gi[:b]) and np.array_equal(res[b][1], gd[:b])
     ix.close()
+
+
+@pytest.mark.parametrize("dim,k", [(8192, 5), (32768, 5), (32768, 1000)])
+def test_largest_dimensions(hip_lib, oracle_mod, dim, k):
+    """The generic scan keeps the query in LDS: dim up to 32 768 (128 KiB) beside k = 1000 lists (32 KiB)
+    is the whole 160 KiB; beyond that vdb_create refuses."""
+    rng = np.random.default_rng(dim + k)
+    n = 1200
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    q = rows[[7, 900]] + 0.01 * rng.standard_normal((2, dim)).astype(np.float32)
+    rows_n = oracle_mod.normalize_rows(rows)
+    for dtype, kp in (("f32", 0), ("bf16", min(1024, 4 * k))):
+        ix = FlatIndex(dim, dtype)
+        ix.add(rows)
+        idx, dist = ix.search(q, k, kp)
+        r_idx, r_dist, r_sc = oracle_mod.exact_topk(rows_n, q, k)
+        check_topk(idx, dist, r_idx, r_dist, r_sc, rows_n, _qn(oracle_mod, q), what=f"dim={dim} k={k} {dtype}")
+        ix.close()
+    with pytest.raises(Exception, match="dim must be"):
+        FlatIndex(32769, "f32")

@@ -583,7 +583,7 @@ extern "C" {
 
 int vdb_create(vdb_t** out, int dim, int dtype, int keep_f32, int device_id) {
   if (!out) return fail(nullptr, VDB_ERR_ARG, "vdb_create: out is NULL");
-  if (dim <= 0 || dim > 65536) return fail(nullptr, VDB_ERR_ARG, "vdb_create: dim must be in [1,65536]");
+  if (dim <= 0 || dim > 32768) return fail(nullptr, VDB_ERR_ARG, "vdb_create: dim must be in [1,32768]");   // the generic scan keeps the query in LDS: 128 KiB + lists
   if (dtype != VDB_F32 && dtype != VDB_BF16) return fail(nullptr, VDB_ERR_ARG, "vdb_create: dtype must be 0 (f32) or 1 (bf16)");
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
