@@ -694,3 +694,30 @@ def test_largest_dimensions(hip_lib, oracle_mod, dim, k):
         ix.close()
     with pytest.raises(Exception, match="dim must be"):
         FlatIndex(32769, "f32")
+
+
+def test_mfma_small_stores_and_odd_batches(hip_lib, oracle_mod):
+    """The batched path at the small end: stores of 16..48 tiles (4 096 rows is its minimum), batches that
+    pad to one or two query tiles of either kernel, k' from 4 to 64 (k' >= 4k: with fewer candidates the bf16
+    ranking may legitimately miss a boundary row, which is what the rerank margin is for)."""
+    rng = np.random.default_rng(99)
+    dim = 768
+    for n, b, k, kp in ((4096, 3, 1, 4), (4097, 17, 10, 40), (5000, 130, 5, 64), (8191, 257, 10, 40), (12345, 40, 16, 64)):
+        rows = rng.standard_normal((n, dim)).astype(np.float32)
+        rows[n // 2] = rows[n // 3]                                   # one exact duplicate pair
+        q = rows[rng.integers(0, n, b)] + 0.1 * rng.standard_normal((b, dim)).astype(np.float32)
+        rows_n = oracle_mod.normalize_rows(rows)
+        ix = FlatIndex(dim, "bf16", True)
+        ix.add(rows)
+        ix.set_option("mfma_cost_model", 0)
+        idx, dist = ix.search(q, k, kp)
+        assert ix.get_stat("mfma_last_hits") > 0, (n, b)                # served by the MFMA path
+        r_idx, r_dist, r_sc = oracle_mod.exact_topk(rows_n, q, k)
+        swaps = check_topk(idx, dist, r_idx, r_dist, r_sc, rows_n, _qn(oracle_mod, q), what=f"n={n} b={b} k={k} kp={kp}")
+        if kp >= 4 * k:
+            assert recall_at_k(idx, r_idx) >= 1.0 - swaps / idx.size - 1e-12
+        ix.set_option("batch_mfma_min_b", 1 << 20)
+        gi, gd = ix.search(q, k, kp)                                    # the GEMV scan on the same store
+        if kp >= 4 * k:
+            assert np.array_equal(gi, idx) and np.array_equal(gd, dist)
+        ix.close()
