@@ -705,12 +705,12 @@ int vdb_search(vdb_t* h, const float* queries_host, int b, int k, int kp, int64_
   // memory is staged by the runtime and costs ~10 us each at any size; three of them were half of a
   // 41 us query against a 14 777-row store.
   const size_t pin_need = qbytes + ibytes + dbytes;
-  const bool pinned = pin_need <= ((size_t)1 << 20);
+  bool pinned = pin_need <= ((size_t)1 << 20);
   if (pinned && h->pin_bytes < pin_need) {
     if (h->pin) { HIP_TRY(h, hipStreamSynchronize(h->stream)); HIP_TRY(h, hipHostFree(h->pin)); h->pin = nullptr; h->pin_bytes = 0; }
     const size_t want = std::max(pin_need, (size_t)65536);
-    HIP_TRY(h, hipHostMalloc(&h->pin, want, hipHostMallocDefault));
-    h->pin_bytes = want;
+    if (hipHostMalloc(&h->pin, want, hipHostMallocDefault) == hipSuccess) h->pin_bytes = want;
+    else { (void)hipGetLastError(); h->pin = nullptr; pinned = false; }   // no pinned memory to be had: the pageable path still works
   }
   if (pinned) {
     memcpy(h->pin, queries_host, qbytes);
