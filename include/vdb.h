@@ -127,9 +127,10 @@ int vdb_search_dev(vdb_t* h, const float* queries_dev, int b, int k, int rerank_
  * evaluates the metadata predicate into a bitmap, one bit per stored row of THIS
  * handle in insertion order (bit r = word r/32, bit r%32; the row offset does
  * not shift it): set = the row may be returned.  n_bits must equal vdb_count.
- * The scan skips ineligible rows before top-k selection, so the result is the
- * exact top-k of the eligible rows, -1/+inf padded when fewer than k are
- * eligible.  Runs on the GEMV scan for every batch size. */
+ * The scan skips ineligible rows before top-k selection (and does not read
+ * 4..16-row tiles without an eligible row at all), so the result is the exact
+ * top-k of the eligible rows, -1/+inf padded when fewer than k are eligible.
+ * Runs on the GEMV scan for every batch size. */
 int vdb_search_masked(vdb_t* h, const float* queries_host, int b, int k, int rerank_kprime,
                       const uint32_t* allow_bits_host, int64_t n_bits,
                       int64_t* out_idx_host, float* out_dist_host);

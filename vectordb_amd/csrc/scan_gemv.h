@@ -146,10 +146,22 @@ __global__ __launch_bounds__(kScanThreads) void scan_topk_kernel(const void* __r
   const long long gw = (long long)blockIdx.x * kScanWaves + w;
   const long long nw = (long long)gridDim.x * kScanWaves;
 
+  // eligibility bits of a tile's rows (bit j = row tile*RPT + j), fetched ONE TILE AHEAD so that the (wave-uniform)
+  // load hides behind the current tile; a tile with no eligible row is not read at all, so a selective where=
+  // filter streams only the tiles it needs (1 % eligible at random: 92 % of the 8-row tiles are skipped)
+  constexpr unsigned kTileBits = RPT == 32 ? 0xffffffffu : ((1u << RPT) - 1u);
+  auto tile_bits = [&](long long t) -> unsigned {
+    const long long r0 = t * RPT;
+    return (allow[r0 >> 5] >> (unsigned)(r0 & 31)) & kTileBits;
+  };
+  unsigned elig_next = (allow && gw < n_tiles) ? tile_bits(gw) : kTileBits;
+
   for (long long tile = gw; tile < n_tiles; tile += nw) {
+    const unsigned elig = elig_next;
+    if (allow && tile + nw < n_tiles) elig_next = tile_bits(tile + nw);
+    if (elig == 0u) continue;
     const long long c0 = tile * (long long)(RPT * CPR) + lane;
     const long long row0 = tile * RPT;
-    const unsigned elig = allow ? (allow[row0 >> 5] >> (unsigned)(row0 & 31)) : 0xffffffffu;
     u32x4 v[U * L];
     if ((tile + 1) * RPT <= (long long)n_rows) {
 #pragma unroll
