@@ -255,7 +255,8 @@ class Collection:
         b = q.shape[0]
         if allowed.size == 0:
             return [np.zeros(0, np.int64)] * b, [np.zeros(0, np.float32)] * b
-        if 250 * allowed.size >= ((b + 3) // 4) * mask.size:
+        passes = (b + 3) // 4      # up to 4 queries are one masked pass, which reads only the tiles with an eligible row
+        if passes == 1 or 250 * allowed.size >= passes * mask.size:
             k = min(n_results, allowed.size)
             idx, dist = self._index.search_masked(q, k, mask, self._kprime(k))
             rows = [idx[i][idx[i] >= 0] for i in range(b)]
