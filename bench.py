@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--mfma-min-b", type=int, default=0, help="diagnostic: smallest batch sent to the MFMA path")
     ap.add_argument("--clusters", type=int, default=0, help="synthetic clusters (default sqrt(rows))")
     ap.add_argument("--time-every", type=int, default=4, help="HIP-event timing of the kernel on every Nth step (an event record idles the queue ~6 us)")
+    ap.add_argument("--two-phase", action="store_true", help="diagnostic: the merge/rerank of a batch moves to the exchange's side stream")
     ap.add_argument("--no-skip-sample", action="store_true", help="diagnostic: the last MFMA pass re-multiplies the sampled tiles")
     ap.add_argument("--mfma-split", type=int, default=0, help="diagnostic: mfma_split_x1000 option")
     ap.add_argument("--ablate", type=int, default=0, help="diagnostic: MFMA kernel ablation bits (results invalid)")
@@ -125,7 +126,7 @@ def main():
                       base_n_clusters=spec.n_clusters, base_noise=0.3)
 
     t_build = time.perf_counter()
-    sh = ShardedIndex(dim, args.dtype, True, device=device, force_collective=args.force_collective)
+    sh = ShardedIndex(dim, args.dtype, True, device=device, force_collective=args.force_collective, two_phase=args.two_phase)
     sh.add_synth_partition(n, spec)
     lo, hi = shard_range(n, rank, world)
     n_local = hi - lo

@@ -121,6 +121,16 @@ int vdb_search(vdb_t* h, const float* queries_host, int b, int k, int rerank_kpr
 int vdb_search_dev(vdb_t* h, const float* queries_dev, int b, int k, int rerank_kprime,
                    int64_t* out_idx_dev, float* out_dist_dev, void* stream);
 
+/* vdb_search_dev in two phases, for callers that pipeline batches (the multi-GPU exchange of SURVEY 8e):
+ * phase 1 normalises the queries and scans the corpus (the HBM-bound part), phase 2 merges the partial lists,
+ * reranks and ranks.  The phases may run on different streams (the caller orders phase 2 after phase 1 with an
+ * event), and `slot` (0 or 1) names one of two workspace sets, so that phase 2 of batch i overlaps phase 1 of
+ * batch i+1.  A slot holds one pending scan.  Only batches that run as ONE scan round split: 1..64 queries on
+ * the GEMV scan; otherwise vdb_search_scan_dev returns VDB_ERR_STATE and does nothing (use vdb_search_dev).
+ * Same results as vdb_search_dev.  No counterpart in the reference (its queries are synchronous, one at a time). */
+int vdb_search_scan_dev(vdb_t* h, const float* queries_dev, int b, int k, int rerank_kprime, int slot, void* stream);
+int vdb_search_finish_dev(vdb_t* h, int slot, int64_t* out_idx_dev, float* out_dist_dev, void* stream);
+
 /* Replaces collection.query(..., where=where_filter) (src/vectordb.py:230 and
  * :259-264: find_similar_products passes its where_filter through to Chroma,
  * which pre-filters by metadata and searches the matching rows only).  The host

@@ -201,6 +201,8 @@ struct vdb {
   float* rows;       /* normalised fp32 (dtype f32, or bf16 with keep_f32) */
   uint16_t* rows16;  /* bf16 bits (dtype bf16)                             */
   double last_bytes;
+  float* split_q[2];  /* queries of a pending two-phase search, per slot */
+  int split_b[2], split_k[2], split_kp[2];
   char err[256];
 };
 static char g_err[256];
@@ -223,7 +225,7 @@ int vdb_create(vdb_t** out, int dim, int dtype, int keep_f32, int device_id) {
 }
 void vdb_destroy(vdb_t* h) {
   if (!h) return;
-  free(h->rows); free(h->rows16); free(h);
+  free(h->rows); free(h->rows16); free(h->split_q[0]); free(h->split_q[1]); free(h);
 }
 const char* vdb_last_error(vdb_t* h) { return h ? h->err : g_err; }
 
@@ -331,6 +333,30 @@ int vdb_search(vdb_t* h, const float* queries, int b, int k, int kp, int64_t* ou
 int vdb_search_dev(vdb_t* h, const float* q, int b, int k, int kp, int64_t* oi, float* od, void* stream) {
   (void)stream;
   return vdb_search(h, q, b, k, kp, oi, od);
+}
+/* two-phase form: the CPU twin keeps the queries in phase 1 and searches in phase 2 */
+int vdb_search_scan_dev(vdb_t* h, const float* q, int b, int k, int kp, int slot, void* stream) {
+  (void)stream;
+  if (!h) return VDB_ERR_ARG;
+  if (slot != 0 && slot != 1) return fail(h, VDB_ERR_ARG, "search_scan: slot must be 0 or 1");
+  int rc = check_search_args(h, q, b, k, kp, h, h);
+  if (rc) return rc;
+  if (b < 1 || b > 64 || h->n == 0) return fail(h, VDB_ERR_STATE, "search_scan: this batch does not split: use vdb_search_dev");
+  free(h->split_q[slot]);
+  h->split_q[slot] = (float*)malloc(sizeof(float) * (size_t)b * h->dim);
+  memcpy(h->split_q[slot], q, sizeof(float) * (size_t)b * h->dim);
+  h->split_b[slot] = b; h->split_k[slot] = k; h->split_kp[slot] = kp;
+  return VDB_OK;
+}
+int vdb_search_finish_dev(vdb_t* h, int slot, int64_t* oi, float* od, void* stream) {
+  (void)stream;
+  if (!h) return VDB_ERR_ARG;
+  if (slot != 0 && slot != 1) return fail(h, VDB_ERR_ARG, "search_finish: slot must be 0 or 1");
+  if (!h->split_q[slot]) return fail(h, VDB_ERR_STATE, "search_finish: no scan is pending in this slot");
+  int rc = search_all(h, h->split_q[slot], h->split_b[slot], h->split_k[slot], h->split_kp[slot], NULL, oi, od);
+  free(h->split_q[slot]);
+  h->split_q[slot] = NULL;
+  return rc;
 }
 /* where-filtered query: only rows whose bit is set are eligible */
 int vdb_search_masked(vdb_t* h, const float* queries, int b, int k, int kp, const uint32_t* allow_bits, int64_t n_bits,

@@ -424,11 +424,12 @@ def test_packed_allgather_layout_merge(hip_lib, oracle_mod, corpus20k):
     sh.close()
 
 
-def test_sharded_exchange_on_side_stream(hip_lib, oracle_mod, corpus20k):
+@pytest.mark.parametrize("two_phase", [False, True])
+def test_sharded_exchange_on_side_stream(hip_lib, oracle_mod, corpus20k, two_phase):
     """The N>1 code path on one GPU: RCCL with a single rank, exchange forced on.  The
-    all-gather + merge run on the side stream; wait=False results are valid after
-    wait_results(), buffer sets are recycled every second call, and every answer equals
-    the plain single-index answer."""
+    all-gather + merge run on the side stream (with two_phase, the batch's own merge/rerank
+    too); wait=False results are valid after wait_results(), buffer sets are recycled every
+    second call, and every answer equals the plain single-index answer."""
     import socket
     import torch
     import torch.distributed as dist
@@ -440,7 +441,7 @@ def test_sharded_exchange_on_side_stream(hip_lib, oracle_mod, corpus20k):
         port = s.getsockname()[1]
     dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
-        sh = ShardedIndex(dim, "bf16", True, device=torch.device("cuda", 0), force_collective=True)
+        sh = ShardedIndex(dim, "bf16", True, device=torch.device("cuda", 0), force_collective=True, two_phase=two_phase)
         sh.add_synth_partition(n, spec)
         plain = FlatIndex(dim, "bf16", True)
         plain.add_synth(0, n, spec)
@@ -721,3 +722,46 @@ def test_mfma_small_stores_and_odd_batches(hip_lib, oracle_mod):
         if kp >= 4 * k:
             assert np.array_equal(gi, idx) and np.array_equal(gd, dist)
         ix.close()
+
+
+@pytest.mark.parametrize("dtype,kp", [("f32", 0), ("bf16", 40)])
+def test_two_phase_search_equals_one_call(hip_lib, oracle_mod, corpus20k, dtype, kp):
+    """vdb_search_scan_dev + vdb_search_finish_dev (phase 2 on another stream, both workspace slots in flight)
+    return bit for bit what vdb_search_dev returns; batches that do not split say so and do nothing."""
+    import torch
+    n, dim, spec, rows, queries = corpus20k
+    ix = FlatIndex(dim, dtype)
+    ix.add_synth(0, n, spec)
+    rng = np.random.default_rng(7)
+    main, side = torch.cuda.current_stream(), torch.cuda.Stream()
+    for b in (1, 3, 9, 64):
+        qa = torch.from_numpy(rows[rng.integers(0, n, b)] + 0.05 * rng.standard_normal((b, dim)).astype(np.float32)).cuda()
+        qb = torch.from_numpy(rows[rng.integers(0, n, b)] + 0.05 * rng.standard_normal((b, dim)).astype(np.float32)).cuda()
+        ref = []
+        for q in (qa, qb):
+            ri = torch.empty((b, 10), dtype=torch.int64, device="cuda"); rd = torch.empty((b, 10), dtype=torch.float32, device="cuda")
+            ix.set_option("batch_mfma_min_b", 1 << 20)                    # the reference call on the GEMV scan as well
+            ix.search_device(q.data_ptr(), b, 10, kp, ri.data_ptr(), rd.data_ptr(), main.cuda_stream)
+            ref.append((ri, rd))
+        torch.cuda.synchronize()
+        outs = []
+        for slot, q in enumerate((qa, qb)):                               # two scans queued back to back, one per slot
+            assert ix.search_scan_device(q.data_ptr(), b, 10, kp, slot, main.cuda_stream)
+            ev = torch.cuda.Event(); ev.record(main)
+            oi = torch.empty((b, 10), dtype=torch.int64, device="cuda"); od = torch.empty((b, 10), dtype=torch.float32, device="cuda")
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                ix.search_finish_device(slot, oi.data_ptr(), od.data_ptr(), side.cuda_stream)
+            outs.append((oi, od))
+        torch.cuda.synchronize()
+        for (oi, od), (ri, rd) in zip(outs, ref):
+            assert torch.equal(oi, ri) and torch.equal(od, rd), (dtype, b)
+        ix.set_option("batch_mfma_min_b", 3)
+    q65 = torch.zeros((65, dim), dtype=torch.float32, device="cuda")
+    assert not ix.search_scan_device(q65.data_ptr(), 65, 10, kp, 0, main.cuda_stream)          # more than one scan round
+    if dtype == "bf16":
+        ix.set_option("mfma_cost_model", 0)
+        assert not ix.search_scan_device(q65.data_ptr(), 32, 10, kp, 0, main.cuda_stream)      # would take the MFMA path
+    with pytest.raises(Exception):
+        ix.search_finish_device(0, q65.data_ptr(), q65.data_ptr(), main.cuda_stream)           # nothing pending
+    ix.close()

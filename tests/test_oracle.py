@@ -98,6 +98,16 @@ def test_cpu_abi_store_roundtrip(oracle_lib, oracle_mod, tmp_path):
     assert sorted(mi[0, :2].tolist()) == [9, 200] and np.all(mi[:, 2:] == -1) and np.all(np.isinf(md[:, 2:]))
     with pytest.raises(Exception):
         ix.search_masked(q, 7, np.ones(299, bool))
+    # two-phase form (phase 1 scan, phase 2 finish): same answer as the one-call search, per slot
+    qc = np.ascontiguousarray(q, np.float32)
+    for slot in (0, 1):
+        ti = np.empty((2, 7), np.int64); td = np.empty((2, 7), np.float32)
+        assert ix.search_scan_device(qc.ctypes.data, 2, 7, 0, slot)
+        ix.search_finish_device(slot, ti.ctypes.data, td.ctypes.data)
+        assert np.array_equal(ti, idx) and np.array_equal(td, dist)
+        with pytest.raises(Exception):
+            ix.search_finish_device(slot, ti.ctypes.data, td.ctypes.data)      # nothing pending any more
+    assert not ix.search_scan_device(np.zeros((65, 40), np.float32).ctypes.data, 65, 7, 0, 0)   # more than one scan round: does not split
     with pytest.raises(Exception):
         ix.search(q, 0)
     with pytest.raises(Exception):

@@ -23,6 +23,7 @@ VDB_MAX_K = 1024
 SYMBOLS = (
     "vdb_create", "vdb_destroy", "vdb_last_error", "vdb_reserve", "vdb_set_row_offset",
     "vdb_add", "vdb_add_dev", "vdb_count", "vdb_search", "vdb_search_dev", "vdb_search_masked", "vdb_search_masked_dev",
+    "vdb_search_scan_dev", "vdb_search_finish_dev",
     "vdb_merge_topk_dev",
     "vdb_selfjoin", "vdb_fetch", "vdb_save", "vdb_load", "vdb_last_timing", "vdb_timing_stats", "vdb_set_option", "vdb_get_stat",
     "vdb_synth_rows_dev", "vdb_add_synth",
@@ -64,6 +65,8 @@ def _declare(lib: C.CDLL) -> C.CDLL:
     lib.vdb_search_dev.argtypes = [vp, pf, i32, i32, i32, pi64, pf, vp]
     lib.vdb_search_masked.argtypes = [vp, pf, i32, i32, i32, vp, i64, pi64, pf]
     lib.vdb_search_masked_dev.argtypes = [vp, pf, i32, i32, i32, vp, i64, pi64, pf, vp]
+    lib.vdb_search_scan_dev.argtypes = [vp, pf, i32, i32, i32, i32, vp]
+    lib.vdb_search_finish_dev.argtypes = [vp, i32, pi64, pf, vp]
     lib.vdb_merge_topk_dev.argtypes = [vp, pf, i64, pi64, i64, i32, i32, i32, pi64, pf, vp]
     lib.vdb_selfjoin.argtypes = [vp, i64, i64, i32, i32, i32, pi64, pf]
     lib.vdb_fetch.argtypes = [vp, pi64, i64, pf]

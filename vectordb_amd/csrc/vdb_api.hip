@@ -57,6 +57,8 @@ struct vdb {
   int mfma_ablate = 0;   // diagnostic: skip parts of the MFMA kernel (wrong results, timing only)
   // workspaces (grown on demand)
   DevBuf w_q, w_part_s, w_part_i, w_part2_s, w_part2_i, w_stage, w_out_i, w_out_d, w_idx, w_mfma;
+  DevBuf w_q1, w_part_s1, w_part_i1, w_part2_s1, w_part2_i1;   // second set: slot 1 of the two-phase search
+  struct Split { bool pending = false; int b = 0, k = 0, kp = 0, grid = 0; hipEvent_t* ev = nullptr; bool ev_on = false; } split[2];
   DevBuf w_cand_s, w_cand_i, w_cand_cnt, w_thr, w_dense, w_list_s, w_list_i;   // append-path state
   DevBuf w_seed_s, w_seed_i;      // the sample pass's sorted list (seeds the final selection)
   int mfma_skip_sample = 1;       // 1: the last of two passes leaves out the sample pass's tiles
@@ -219,14 +221,22 @@ void launch_merge(int e, const float* is, const int* ii, int n_cand, int cpb, in
   }
 }
 
+// The GEMV path's workspaces exist twice: slot 1 lets phase 2 of one batch (merge, rerank) run on another
+// stream while phase 1 of the next batch (normalise, scan) fills slot 0, and vice versa.
+struct WsSet { DevBuf *q, *ps, *pi, *p2s, *p2i; };
+WsSet ws_of(vdb_t* h, int slot) {
+  return slot ? WsSet{&h->w_q1, &h->w_part_s1, &h->w_part_i1, &h->w_part2_s1, &h->w_part2_i1}
+              : WsSet{&h->w_q, &h->w_part_s, &h->w_part_i, &h->w_part2_s, &h->w_part2_i};
+}
+
 // Reduce the [b][n_parts][kk] partial lists of one query chunk to the b x k outputs:
 // hierarchical merge, then fp32 rerank (kp != 0) or plain ranking.
-int finish_search(vdb_t* h, int b, int n_parts, int kk, int k, int kp, const float* qn, int64_t* oi, float* od,
+int finish_search(vdb_t* h, const WsSet& W, int b, int n_parts, int kk, int k, int kp, const float* qn, int64_t* oi, float* od,
                   hipStream_t st) {
-  float* cur_s = (float*)h->w_part_s.p;
-  int* cur_i = (int*)h->w_part_i.p;
-  float* oth_s = (float*)h->w_part2_s.p;
-  int* oth_i = (int*)h->w_part2_i.p;
+  float* cur_s = (float*)W.ps->p;
+  int* cur_i = (int*)W.pi->p;
+  float* oth_s = (float*)W.p2s->p;
+  int* oth_i = (int*)W.p2i->p;
   const int e = entries_for(kk);
   int lists = n_parts;
   if (e == 1) {
@@ -455,17 +465,74 @@ bool mfma_is_faster(int b, int n_rows) {
   return mfma < gemv;
 }
 
+constexpr int kQChunk = 64;   // queries per scan/merge round of the GEMV path
+
+// grid: enough blocks to fill the chip, never more tiles than work
+int gemv_grid(vdb_t* h) {
+  const int rows_per_block_min = 64;
+  const int64_t grid = (int64_t)h->n_cu * h->scan_blocks_per_cu;
+  return (int)std::max<int64_t>(1, std::min<int64_t>(grid, (h->n + rows_per_block_min - 1) / rows_per_block_min));
+}
+
+int ensure_parts(vdb_t* h, const WsSet& W, size_t part_elems) {
+  int rc;
+  if ((rc = ensure(h, *W.ps, part_elems * 4))) return rc;
+  if ((rc = ensure(h, *W.pi, part_elems * 4))) return rc;
+  if ((rc = ensure(h, *W.p2s, part_elems * 4))) return rc;
+  if ((rc = ensure(h, *W.p2i, part_elems * 4))) return rc;
+  return VDB_OK;
+}
+
+// The scan passes of one chunk of cb <= 64 normalised queries: partial lists [cb][grid][kk] into W.
+int gemv_scan_chunk(vdb_t* h, const WsSet& W, const float* qn, int cb, int kk, int64_t self_row0, const unsigned* allow,
+                    int grid, hipStream_t st) {
+  const int e = entries_for(kk);
+  const bool bf16 = h->dtype == VDB_BF16;
+  const void* rows = bf16 ? (const void*)h->rows_bf16 : (const void*)h->rows_f32;
+  const int n_rows = (int)h->n;
+  const bool fast_dim = (h->ld == h->dim) && (h->dim == 768 || h->dim == 384);
+  int q = 0;
+  while (q < cb) {
+    int qb = 1;
+    if (fast_dim && e <= 2) { if (cb - q >= 4) qb = 4; else if (cb - q >= 2) qb = 2; }
+    ScanArgs a;
+    a.rows = rows; a.n_rows = n_rows; a.qn = qn + (size_t)q * h->ld; a.kk = kk;
+    a.self0 = self_row0 >= 0 ? (int)(self_row0 + q) : -1;
+    a.allow = allow;
+    a.part_s = (float*)W.ps->p + (size_t)q * grid * kk;
+    a.part_i = (int*)W.pi->p + (size_t)q * grid * kk;
+    a.grid = grid; a.st = st;
+    a.smem = (size_t)kScanWaves * qb * kk * 8;
+    bool ok;
+    const bool nt = h->scan_nt_loads != 0;
+    if (fast_dim) {
+      if (h->dim == 768) ok = bf16 ? launch_scan_dim<bf16_t, 768>(a, qb, e, nt) : launch_scan_dim<float, 768>(a, qb, e, nt);
+      else ok = bf16 ? launch_scan_dim<bf16_t, 384>(a, qb, e, nt) : launch_scan_dim<float, 384>(a, qb, e, nt);
+    } else {
+      a.smem = (size_t)kScanWaves * kk * 8 + (size_t)h->ld * 4;
+      ok = bf16 ? launch_scan_generic<bf16_t>(a, h->ld, e, nt) : launch_scan_generic<float>(a, h->ld, e, nt);
+    }
+    if (!ok) return fail(h, VDB_ERR_ARG, "search: unsupported k for this path");
+    HIP_TRY(h, hipGetLastError());
+    h->last_bytes += (double)n_rows * h->ld * (bf16 ? 2 : 4);
+    q += qb;
+  }
+  return VDB_OK;
+}
+
+// Does a batch take the MFMA path?  (bf16 store, fast dim, enough queries that it beats ceil(b/4) GEMV passes)
+bool takes_mfma_path(vdb_t* h, int b, int kk, bool masked) {
+  return !masked && h->dtype == VDB_BF16 && h->dim == 768 && h->ld == 768 && b >= h->batch_mfma_min_b && mfma_path_supported(kk) &&
+         h->n >= 4096 && (!h->mfma_cost_model || mfma_is_faster(b, (int)h->n));
+}
+
 // Core search over device-resident, already *normalised* queries qn [b][ld].
 // self_row0 >= 0: query q excludes row self_row0+q.
 // allow != nullptr: device bitmap of eligible rows (GEMV scan only).
 int search_core(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_row0, int64_t* out_idx,
                 float* out_dist, hipStream_t st, const unsigned* allow = nullptr) {
   const int kk = kp ? kp : k;
-  const int e = entries_for(kk);
-  const bool bf16 = h->dtype == VDB_BF16;
-  const void* rows = bf16 ? (const void*)h->rows_bf16 : (const void*)h->rows_f32;
   const int n_rows = (int)h->n;
-  const bool fast_dim = (h->ld == h->dim) && (h->dim == 768 || h->dim == 384);
 
   h->ev_on = h->timing_every <= 1 || (h->n_calls % h->timing_every) == 0;
   h->n_calls++;
@@ -486,63 +553,23 @@ int search_core(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
     return VDB_OK;
   }
 
-  // MFMA batched path (bf16 store, fast dim, enough queries that it beats ceil(b/4) GEMV passes)
-  if (!allow && bf16 && h->dim == 768 && h->ld == 768 && b >= h->batch_mfma_min_b && mfma_path_supported(kk) && n_rows >= 4096 &&
-      (!h->mfma_cost_model || mfma_is_faster(b, n_rows))) {
-    int rc = mfma_search(h, qn, b, k, kp, self_row0, out_idx, out_dist, st);
-    return rc;
-  }
+  if (takes_mfma_path(h, b, kk, allow != nullptr)) return mfma_search(h, qn, b, k, kp, self_row0, out_idx, out_dist, st);
 
-  // grid: enough blocks to fill the chip, never more tiles than work
-  const int rows_per_block_min = 64;
-  int grid = h->n_cu * h->scan_blocks_per_cu;
-  grid = (int)std::max<int64_t>(1, std::min<int64_t>(grid, ((int64_t)n_rows + rows_per_block_min - 1) / rows_per_block_min));
-
+  const int grid = gemv_grid(h);
+  const WsSet W = ws_of(h, 0);
   // queries are processed in chunks so the partial buffers stay small
-  const int qchunk = 64;
-  const int cb_max = std::min(b, qchunk);
-  const size_t part_elems = (size_t)cb_max * grid * kk;
+  const int cb_max = std::min(b, kQChunk);
   int rc;
-  if ((rc = ensure(h, h->w_part_s, part_elems * 4))) return rc;
-  if ((rc = ensure(h, h->w_part_i, part_elems * 4))) return rc;
-  if ((rc = ensure(h, h->w_part2_s, part_elems * 4))) return rc;
-  if ((rc = ensure(h, h->w_part2_i, part_elems * 4))) return rc;
-
-  for (int q0 = 0; q0 < b; q0 += qchunk) {
-    const int cb = std::min(qchunk, b - q0);
-    // --- scan passes -------------------------------------------------------
-    int q = 0;
-    while (q < cb) {
-      int qb = 1;
-      if (fast_dim && e <= 2) { if (cb - q >= 4) qb = 4; else if (cb - q >= 2) qb = 2; }
-      ScanArgs a;
-      a.rows = rows; a.n_rows = n_rows; a.qn = qn + (size_t)(q0 + q) * h->ld; a.kk = kk;
-      a.self0 = self_row0 >= 0 ? (int)(self_row0 + q0 + q) : -1;
-      a.allow = allow;
-      a.part_s = (float*)h->w_part_s.p + (size_t)q * grid * kk;
-      a.part_i = (int*)h->w_part_i.p + (size_t)q * grid * kk;
-      a.grid = grid; a.st = st;
-      a.smem = (size_t)kScanWaves * qb * kk * 8;
-      bool ok;
-      const bool nt = h->scan_nt_loads != 0;
-      if (fast_dim) {
-        if (h->dim == 768) ok = bf16 ? launch_scan_dim<bf16_t, 768>(a, qb, e, nt) : launch_scan_dim<float, 768>(a, qb, e, nt);
-        else ok = bf16 ? launch_scan_dim<bf16_t, 384>(a, qb, e, nt) : launch_scan_dim<float, 384>(a, qb, e, nt);
-      } else {
-        a.smem = (size_t)kScanWaves * kk * 8 + (size_t)h->ld * 4;
-        ok = bf16 ? launch_scan_generic<bf16_t>(a, h->ld, e, nt) : launch_scan_generic<float>(a, h->ld, e, nt);
-      }
-      if (!ok) return fail(h, VDB_ERR_ARG, "search: unsupported k for this path");
-      HIP_TRY(h, hipGetLastError());
-      h->last_bytes += (double)n_rows * h->ld * (bf16 ? 2 : 4);
-      q += qb;
-    }
-    if (q0 == 0 && b <= qchunk) if (h->ev_on) HIP_TRY(h, hipEventRecord(h->ev[1], st));
+  if ((rc = ensure_parts(h, W, (size_t)cb_max * grid * kk))) return rc;
+  for (int q0 = 0; q0 < b; q0 += kQChunk) {
+    const int cb = std::min(kQChunk, b - q0);
+    if ((rc = gemv_scan_chunk(h, W, qn + (size_t)q0 * h->ld, cb, kk, self_row0 >= 0 ? self_row0 + q0 : -1, allow, grid, st))) return rc;
+    if (q0 == 0 && b <= kQChunk) if (h->ev_on) HIP_TRY(h, hipEventRecord(h->ev[1], st));
     // --- merge + finish ----------------------------------------------------
-    if ((rc = finish_search(h, cb, grid, kk, k, kp, qn + (size_t)q0 * h->ld, out_idx + (size_t)q0 * k,
+    if ((rc = finish_search(h, W, cb, grid, kk, k, kp, qn + (size_t)q0 * h->ld, out_idx + (size_t)q0 * k,
                             out_dist + (size_t)q0 * k, st))) return rc;
   }
-  if (b > qchunk) if (h->ev_on) HIP_TRY(h, hipEventRecord(h->ev[1], st));  // multi-chunk: scan/merge interleave, report total as scan
+  if (b > kQChunk) if (h->ev_on) HIP_TRY(h, hipEventRecord(h->ev[1], st));  // multi-chunk: scan/merge interleave, report total as scan
   if (h->ev_on) HIP_TRY(h, hipEventRecord(h->ev[2], st));
   if (h->ev_on) h->timing_valid = true;
   return VDB_OK;
@@ -565,10 +592,11 @@ int check_search_args(vdb_t* h, const void* q, int b, int k, int kp, const void*
 }
 
 // normalise raw device queries [b][dim] into the handle's query workspace [b][ld]
-int prep_queries(vdb_t* h, const float* q_dev, int b, hipStream_t st, float** qn) {
-  int rc = ensure(h, h->w_q, (size_t)std::max(b, 1) * h->ld * 4);
+int prep_queries(vdb_t* h, const float* q_dev, int b, hipStream_t st, float** qn, int slot = 0) {
+  DevBuf& wq = slot ? h->w_q1 : h->w_q;
+  int rc = ensure(h, wq, (size_t)std::max(b, 1) * h->ld * 4);
   if (rc) return rc;
-  float* out = (float*)h->w_q.p;
+  float* out = (float*)wq.p;
   const int blocks = std::max(1, std::min((b + 3) / 4, h->n_cu * 8));
   hipLaunchKernelGGL(normalize_rows_kernel, dim3(blocks), dim3(256), 0, st, q_dev, h->dim, (long long)b, h->dim, h->ld, out, (uint16_t*)nullptr);
   HIP_TRY(h, hipGetLastError());
@@ -611,7 +639,7 @@ void vdb_destroy(vdb_t* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  DevBuf* bufs[] = {&h->w_q, &h->w_part_s, &h->w_part_i, &h->w_part2_s, &h->w_part2_i, &h->w_stage, &h->w_out_i, &h->w_out_d, &h->w_idx, &h->w_mfma,
+  DevBuf* bufs[] = {&h->w_q1, &h->w_part_s1, &h->w_part_i1, &h->w_part2_s1, &h->w_part2_i1, &h->w_q, &h->w_part_s, &h->w_part_i, &h->w_part2_s, &h->w_part2_i, &h->w_stage, &h->w_out_i, &h->w_out_d, &h->w_idx, &h->w_mfma,
                     &h->w_cand_s, &h->w_cand_i, &h->w_cand_cnt, &h->w_thr, &h->w_dense, &h->w_list_s, &h->w_list_i, &h->w_mask, &h->w_seed_s, &h->w_seed_i};
   for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
   if (h->pin) (void)hipHostFree(h->pin);
@@ -688,6 +716,57 @@ int vdb_search_dev(vdb_t* h, const float* queries_dev, int b, int k, int kp, int
   float* qn = nullptr;
   if ((rc = prep_queries(h, queries_dev, b, st, &qn))) return rc;
   return search_core(h, qn, b, k, kp, -1, out_idx_dev, out_dist_dev, st);
+}
+
+int vdb_search_scan_dev(vdb_t* h, const float* queries_dev, int b, int k, int kp, int slot, void* stream) {
+  if (!h) return VDB_ERR_ARG;
+  if (slot != 0 && slot != 1) return fail(h, VDB_ERR_ARG, "search_scan: slot must be 0 or 1");
+  int rc = check_search_args(h, queries_dev, b, k, kp, h, h);
+  if (rc) return rc;
+  const int kk = kp ? kp : k;
+  if (b < 1 || b > kQChunk || h->n == 0 || takes_mfma_path(h, b, kk, false))
+    return fail(h, VDB_ERR_STATE, "search_scan: this batch does not split (empty store, more than 64 queries, or the batched MFMA path): use vdb_search_dev");
+  if ((rc = set_device(h))) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  float* qn = nullptr;
+  if ((rc = prep_queries(h, queries_dev, b, st, &qn, slot))) return rc;
+  vdb::Split& sp = h->split[slot];
+  sp.ev_on = h->timing_every <= 1 || (h->n_calls % h->timing_every) == 0;
+  h->n_calls++;
+  if (sp.ev_on) {
+    sp.ev = h->ring.data() + 3 * (size_t)(h->n_timed % (int64_t)(h->ring.size() / 3));
+    h->n_timed++;
+    HIP_TRY(h, hipEventRecord(sp.ev[0], st));
+  }
+  h->last_bytes = 0.0;
+  const int grid = gemv_grid(h);
+  const WsSet W = ws_of(h, slot);
+  if ((rc = ensure_parts(h, W, (size_t)b * grid * kk))) return rc;
+  if ((rc = gemv_scan_chunk(h, W, qn, b, kk, -1, nullptr, grid, st))) return rc;
+  if (sp.ev_on) HIP_TRY(h, hipEventRecord(sp.ev[1], st));
+  sp.pending = true; sp.b = b; sp.k = k; sp.kp = kp; sp.grid = grid;
+  return VDB_OK;
+}
+
+int vdb_search_finish_dev(vdb_t* h, int slot, int64_t* out_idx_dev, float* out_dist_dev, void* stream) {
+  if (!h) return VDB_ERR_ARG;
+  if (slot != 0 && slot != 1) return fail(h, VDB_ERR_ARG, "search_finish: slot must be 0 or 1");
+  vdb::Split& sp = h->split[slot];
+  if (!sp.pending) return fail(h, VDB_ERR_STATE, "search_finish: no scan is pending in this slot");
+  if (!out_idx_dev || !out_dist_dev) return fail(h, VDB_ERR_ARG, "search_finish: NULL buffer");
+  int rc = set_device(h);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const WsSet W = ws_of(h, slot);
+  const int kk = sp.kp ? sp.kp : sp.k;
+  sp.pending = false;
+  if ((rc = finish_search(h, W, sp.b, sp.grid, kk, sp.k, sp.kp, (const float*)W.q->p, out_idx_dev, out_dist_dev, st))) return rc;
+  if (sp.ev_on) {
+    HIP_TRY(h, hipEventRecord(sp.ev[2], st));
+    h->ev = sp.ev;
+    h->timing_valid = true;
+  }
+  return VDB_OK;
 }
 
 int vdb_search(vdb_t* h, const float* queries_host, int b, int k, int kp, int64_t* out_idx, float* out_dist) {

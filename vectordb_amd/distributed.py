@@ -29,11 +29,14 @@ def shard_range(n_total: int, rank: int, world: int) -> Tuple[int, int]:
 
 class ShardedIndex:
     def __init__(self, dim: int, dtype: str = "bf16", keep_f32_for_rerank: bool = True, *,
-                 device: Optional[torch.device] = None, group=None, lib=None, force_collective: bool = False):
+                 device: Optional[torch.device] = None, group=None, lib=None, force_collective: bool = False, two_phase: bool = False):
         self.group = group
         self.force_collective = bool(force_collective) and dist.is_initialized()   # world 1: still run the exchange (tests)
         self._side = None
         self._last_done = None
+        self.two_phase = two_phase
+        self._ws_slot = 0                     # next workspace set of the engine's two-phase search
+        self._ws_done = [None, None]          # the event that ends each set's pending phase 2
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.device = torch.device(device) if device is not None else torch.device("cpu")
@@ -107,7 +110,20 @@ class ShardedIndex:
         local = cur["local"]
         idx_ptr = local.data_ptr()
         dist_ptr = idx_ptr + 8 * b * k
-        self.local.search_device(queries.data_ptr(), b, k, rerank_kprime, idx_ptr, dist_ptr, st)
+        # two_phase (off by default): only the normalisation and the corpus scan stay on the caller's stream; the
+        # merge/rerank/ranking of this batch goes to the side stream with the exchange (vdb_search_scan_dev /
+        # vdb_search_finish_dev, one workspace set per slot).  Measured at the 8-GPU shard size on one MI355X it
+        # LOSES: the next scan runs 25 % longer beside the side stream's small kernels (0.372 vs 0.349 ms/step).
+        split = False
+        slot = self._ws_slot
+        if cuda and collective and not wait and self.two_phase:
+            if self._ws_done[slot] is not None:
+                torch.cuda.current_stream(self.device).wait_event(self._ws_done[slot])   # that set's last phase 2 has finished
+            split = self.local.search_scan_device(queries.data_ptr(), b, k, rerank_kprime, slot, st)
+        if not split:
+            if cuda and self._last_done is not None:
+                torch.cuda.current_stream(self.device).wait_event(self._last_done)   # a pending phase 2 shares slot 0's workspaces
+            self.local.search_device(queries.data_ptr(), b, k, rerank_kprime, idx_ptr, dist_ptr, st)
         if not collective:
             # the local result is already final (same (distance, index) ordering rule as the merge)
             return local[: b * k].view(b, k), local[b * k:].view(torch.float32)[: b * k].view(b, k)
@@ -124,6 +140,8 @@ class ShardedIndex:
         cur["ready"].record(main)
         with torch.cuda.stream(self._side):
             self._side.wait_event(cur["ready"])
+            if split:
+                self.local.search_finish_device(slot, idx_ptr, dist_ptr, self._side.cuda_stream)
             dist.all_gather_into_tensor(gathered, local, group=self.group)
             self.local.merge_topk_device(g_idx + 8 * b * k, g_idx, self.world, b, k, out_idx.data_ptr(),
                                          out_dist.data_ptr(), self._side.cuda_stream,
@@ -131,6 +149,9 @@ class ShardedIndex:
             cur["done"].record(self._side)
         cur["used"] = True
         self._last_done = cur["done"]
+        if split:
+            self._ws_done[slot] = cur["done"]
+            self._ws_slot ^= 1
         if wait:
             main.wait_event(cur["done"])
         return out_idx, out_dist

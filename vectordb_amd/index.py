@@ -130,6 +130,19 @@ class FlatIndex:
                                                   int(allow_bits_ptr), int(n_bits), int(out_idx_ptr), int(out_dist_ptr),
                                                   stream or None))
 
+    def search_scan_device(self, q_ptr: int, b: int, k: int, rerank_kprime: int, slot: int, stream: int = 0) -> bool:
+        """Phase 1 of the two-phase search (normalise + corpus scan) into workspace set `slot` (0/1).
+        Returns False — nothing done — when the batch does not split (use search_device)."""
+        rc = self._lib.vdb_search_scan_dev(self._h, int(q_ptr), int(b), int(k), int(rerank_kprime), int(slot), stream or None)
+        if rc == -5:          # VDB_ERR_STATE: not a batch that splits
+            return False
+        self._chk(rc)
+        return True
+
+    def search_finish_device(self, slot: int, out_idx_ptr: int, out_dist_ptr: int, stream: int = 0) -> None:
+        """Phase 2 (merge, rerank, ranking) of the scan pending in `slot`; may run on another stream."""
+        self._chk(self._lib.vdb_search_finish_dev(self._h, int(slot), int(out_idx_ptr), int(out_dist_ptr), stream or None))
+
     def search_device(self, q_ptr: int, b: int, k: int, rerank_kprime: int, out_idx_ptr: int,
                       out_dist_ptr: int, stream: int = 0) -> None:
         self._chk(self._lib.vdb_search_dev(self._h, int(q_ptr), int(b), int(k), int(rerank_kprime),
