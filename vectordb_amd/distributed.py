@@ -113,7 +113,7 @@ class ShardedIndex:
         # two_phase (off by default): only the normalisation and the corpus scan stay on the caller's stream; the
         # merge/rerank/ranking of this batch goes to the side stream with the exchange (vdb_search_scan_dev /
         # vdb_search_finish_dev, one workspace set per slot).  Measured at the 8-GPU shard size on one MI355X it
-        # LOSES: the next scan runs 25 % longer beside the side stream's small kernels (0.372 vs 0.349 ms/step).
+        # LOSES: the next scan runs 25 % longer beside the side stream's small kernels (0.371 vs 0.322 ms/step).
         split = False
         slot = self._ws_slot
         if cuda and collective and not wait and self.two_phase:
@@ -121,8 +121,11 @@ class ShardedIndex:
                 torch.cuda.current_stream(self.device).wait_event(self._ws_done[slot])   # that set's last phase 2 has finished
             split = self.local.search_scan_device(queries.data_ptr(), b, k, rerank_kprime, slot, st)
         if not split:
-            if cuda and self._last_done is not None:
-                torch.cuda.current_stream(self.device).wait_event(self._last_done)   # a pending phase 2 shares slot 0's workspaces
+            if cuda:                                   # a phase 2 still pending on the side stream reads the workspace sets
+                for ev in self._ws_done:
+                    if ev is not None:
+                        torch.cuda.current_stream(self.device).wait_event(ev)
+                self._ws_done = [None, None]
             self.local.search_device(queries.data_ptr(), b, k, rerank_kprime, idx_ptr, dist_ptr, st)
         if not collective:
             # the local result is already final (same (distance, index) ordering rule as the merge)
