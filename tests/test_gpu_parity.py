@@ -765,3 +765,35 @@ def test_two_phase_search_equals_one_call(hip_lib, oracle_mod, corpus20k, dtype,
     with pytest.raises(Exception):
         ix.search_finish_device(0, q65.data_ptr(), q65.data_ptr(), main.cuda_stream)           # nothing pending
     ix.close()
+
+
+def test_mfma_all_scores_negative_or_zero(hip_lib, oracle_mod):
+    """Thresholds that are not positive (every cosine negative; a store of zero rows): the integer block
+    filter of the pass kernels must stand aside and the float compares decide."""
+    rng = np.random.default_rng(31)
+    n, dim = 6000, 768
+    base = rng.standard_normal(dim).astype(np.float32)
+    rows = -base[None, :] + 0.4 * rng.standard_normal((n, dim)).astype(np.float32)      # all rows point away from `base`
+    for b in (40, 300):                                                                  # 128-wide and 256-wide kernels
+        q = base[None, :] + 0.4 * rng.standard_normal((b, dim)).astype(np.float32)
+        rows_n = oracle_mod.normalize_rows(rows)
+        ix = FlatIndex(dim, "bf16", True)
+        ix.add(rows)
+        ix.set_option("mfma_cost_model", 0)
+        idx, dist = ix.search(q, 10, 40)
+        assert ix.get_stat("mfma_last_hits") > 0
+        r_idx, r_dist, r_sc = oracle_mod.exact_topk(rows_n, q, 10)
+        assert np.all(r_sc < 0)                                                          # the premise: every score negative
+        check_topk(idx, dist, r_idx, r_dist, r_sc, rows_n, _qn(oracle_mod, q), what=f"negative scores b={b}")
+        ix.close()
+    zr = np.zeros((5000, dim), np.float32)
+    zr[:50] = rng.standard_normal((50, dim)).astype(np.float32)                          # 50 real rows, 4 950 zero rows (score 0)
+    ix = FlatIndex(dim, "bf16", True)
+    ix.add(zr)
+    ix.set_option("mfma_cost_model", 0)
+    q = -zr[:40] + 0.01 * rng.standard_normal((40, dim)).astype(np.float32)              # best matches are the zero rows (0 > negative)
+    idx, dist = ix.search(q, 10, 40)
+    r_idx, r_dist, r_sc = oracle_mod.exact_topk(oracle_mod.normalize_rows(zr), q, 10)
+    assert np.allclose(dist, r_dist, atol=2e-6) and np.all(np.diff(dist, axis=1) >= 0)
+    assert np.array_equal(idx, r_idx)                                                    # ties at score 0 broken by row index
+    ix.close()
