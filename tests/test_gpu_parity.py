@@ -797,3 +797,26 @@ def test_mfma_all_scores_negative_or_zero(hip_lib, oracle_mod):
     assert np.allclose(dist, r_dist, atol=2e-6) and np.all(np.diff(dist, axis=1) >= 0)
     assert np.array_equal(idx, r_idx)                                                    # ties at score 0 broken by row index
     ix.close()
+
+
+@pytest.mark.parametrize("dtype,kp", [("f32", 0), ("bf16", 40)])
+def test_nan_and_inf_inputs_behave_like_the_oracle(hip_lib, oracle_lib, dtype, kp):
+    """A stored row holding NaN or Inf normalises to NaN and is never returned; a query holding NaN or Inf
+    returns nothing (-1 / +inf).  Same on the GEMV scan (b = 4), the batched path (b = 40) and the oracle."""
+    rng = np.random.default_rng(3)
+    dim, n = 768, 5000
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    rows[17, 5] = np.nan
+    rows[99, 7] = np.inf
+    q = rows[[3, 17, 99, 200]] + 0.01
+    out = {}
+    for name, lib in (("hip", None), ("ora", oracle_lib)):
+        ix = FlatIndex(dim, dtype, True, lib=lib)
+        ix.add(rows)
+        if lib is None:
+            ix.set_option("mfma_cost_model", 0)
+        out[name] = [ix.search(np.concatenate([q] * (b // 4)), 5, kp) for b in (4, 40)]
+        ix.close()
+    for (hi, hd), (oi, od) in zip(out["hip"], out["ora"]):
+        assert np.array_equal(hi, oi) and np.allclose(hd, od, atol=2e-6)
+        assert not np.isin(hi, [17, 99]).any() and np.all(hi[1] == -1) and np.all(hi[2] == -1) and hi[0, 0] == 3
