@@ -29,9 +29,9 @@
 //   * epilogue: VALU time is what it costs (two waves share a SIMD and reach it together), so it
 //     is a max tree: per 32x32 block the lane's 16 scores reduce to four group maxima and one
 //     block maximum; one ballot per block, then one per hot group of four, and only those four
-//     scores are examined.  A hit waits in its lane's registers until some lane needs a second
-//     place; then all waiting hits reserve their slots at once (one atomic round trip per ~10
-//     hits of the wave, not per hit).
+//     scores are examined (the trees run on the scores' bit patterns, see thr_bits below).  A hit
+//     waits in its lane's registers (two places) until some lane needs a third; then all waiting
+//     hits reserve their slots at once (one atomic round trip per flush, not per hit).
 //
 // Where the time goes (10M x 768, B = 1024, final pass; rocprofv3 PMC, cycles per K-step and CU):
 // MFMA alone 2100 (97 % of the matrix pipe, 2.0 GHz), staging alone 2580 (25 B/clk/CU through the
