@@ -63,7 +63,7 @@ class ShardedIndex:
         self.n_total = n_total
 
     # -- search ----------------------------------------------------------------
-    _RING = 2   # buffer sets per (b, k): lets the exchange of one batch overlap the scan of the next
+    _RING = 4   # buffer sets per (b, k): lets the exchange of one batch overlap the scan of the next ones
 
     def _buffers(self, b: int, k: int):
         key = (b, k)
@@ -89,7 +89,7 @@ class ShardedIndex:
     def search(self, queries: torch.Tensor, k: int, rerank_kprime: int = 0, wait: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
         """queries: [b, dim] fp32 tensor on self.device, identical on every rank.
         Returns (idx [b,k] int64 global rows, dist [b,k] fp32) on every rank.  The
-        returned tensors are reused by the second-next call with the same (b, k).
+        returned tensors are reused by the fourth-next call with the same (b, k).
 
         On a GPU with more than one rank the exchange (all-gather + merge) runs on a
         side stream.  wait=True (default) makes the current stream wait for it, so the
@@ -105,7 +105,10 @@ class ShardedIndex:
         cuda = self.device.type == "cuda"
         collective = self.world > 1 or self.force_collective
         if cuda and collective and cur["used"]:
-            torch.cuda.current_stream(self.device).wait_event(cur["done"])   # this set's previous exchange has finished
+            # this set's previous exchange (four calls ago) must have finished.  The HOST waits for it — it is
+            # normally long done — rather than the stream: a stream-side wait is a barrier packet that idles
+            # the queue ~5 us per step whether or not there is anything to wait for
+            cur["done"].synchronize()
         st = self._stream()
         local = cur["local"]
         idx_ptr = local.data_ptr()
