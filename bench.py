@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """bench.py — BASELINE.json's metric on MI355X: QPS @k=10 over a synthetic
-10M x 768 bf16 corpus (fp32 rerank, k'=40), batch 1 (default) or 1024.
+10M x 768 bf16 corpus (fp32 rerank, k'=40), batch 1 AND batch 1024.
 
   python bench.py --gpus 1 --steps 200 --warmup 20
+  python bench.py --gpus 8                 # launches its own ranks (torch.distributed.run) before any GPU call
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -10,34 +11,82 @@ A "step" is one pass of the hot path over one query batch: normalise the queries
 scan the (row-sharded) corpus with the fused top-k' kernel, merge, fp32 rerank,
 and for N>1 one RCCL all-gather + on-device merge.  The corpus (10M rows in
 total, row-sharded over the ranks: strong scaling) and the queries are resident
-in HBM before the timed region.  Rank 0 prints ONE JSON line.
+in HBM before the timed region.  Rank 0 prints ONE JSON line: the headline fields
+are the batch-1 workload (the north-star target), `batch1024` holds the other half
+of the metric (MFMA path) timed in the same run.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
-import numpy as np
-import torch
-import torch.distributed as dist
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-from vectordb_amd import SynthSpec  # noqa: E402
-from vectordb_amd.distributed import ShardedIndex, shard_range  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_BF16_PEAK_TFLOPS = 2500.0
 
 
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--rows", type=int, default=10_000_000, help="total corpus rows (BASELINE: 10M)")
+    ap.add_argument("--dim", type=int, default=768)
+    ap.add_argument("--batch", type=int, default=1, help="queries per step of the headline workload (BASELINE: 1 and 1024)")
+    ap.add_argument("--batch2", type=int, default=1024, help="second workload timed in the same run (0 = none)")
+    ap.add_argument("--steps2", type=int, default=20, help="timed steps of the second workload (at most --steps)")
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--kprime", type=int, default=40)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--blocks-per-cu", type=int, default=0)
+    ap.add_argument("--nt", type=int, default=-1)
+    ap.add_argument("--force-collective", action="store_true",
+                    help="diagnostic, 1 GPU: run the all-gather + merge exchange with a single-rank RCCL group")
+    ap.add_argument("--sync-exchange", action="store_true", help="diagnostic: wait for each batch's exchange (no overlap)")
+    ap.add_argument("--mfma-min-b", type=int, default=0, help="diagnostic: smallest batch sent to the MFMA path")
+    ap.add_argument("--clusters", type=int, default=0, help="synthetic clusters (default sqrt(rows))")
+    ap.add_argument("--time-every", type=int, default=4, help="HIP-event timing of the kernel on every Nth step (an event record idles the queue ~6 us)")
+    ap.add_argument("--two-phase", action="store_true", help="diagnostic: the merge/rerank of a batch moves to the exchange's side stream")
+    ap.add_argument("--no-skip-sample", action="store_true", help="diagnostic: the last MFMA pass re-multiplies the sampled tiles")
+    ap.add_argument("--mfma-split", type=int, default=0, help="diagnostic: mfma_split_x1000 option")
+    ap.add_argument("--ablate", type=int, default=0, help="diagnostic: MFMA kernel ablation bits (results invalid)")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE", help="diagnostic: vdb_set_option on the local shard")
+    return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks with torch.distributed.run as a CHILD process and
+    relay its exit code.  Nothing in this process has touched the GPU yet (device_count() does not initialise it)."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but this node shows {have} GPU(s)")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def cpu_baseline(dim, k, target_rows, seed, budget_s=12.0):
     """The CPU oracle (a port of the reference's algorithm: exact cosine top-k, fp32 storage,
-    fp64 accumulate, OpenMP over rows) timed on a bounded sample of the same workload."""
+    fp64 accumulate, OpenMP over rows) and numpy's BLAS brute force (SURVEY 8d baseline (a)), both timed on the first
+    1M rows of the same corpus with the same queries; the 10M figure is that rate scaled linearly (a linear scan)."""
+    import numpy as np
     from oracle import oracle
-    sample_rows = 400_000
-    spec = SynthSpec(seed=seed, kind=1, n_clusters=int(np.sqrt(target_rows)), noise=0.3)
+    from vectordb_amd import SynthSpec
+    sample_rows = min(1_000_000, target_rows)
+    spec = SynthSpec(seed=seed, kind=1, n_clusters=max(1, int(np.sqrt(target_rows))), noise=0.3)
     rows = oracle.normalize_rows(oracle.synth_rows(0, sample_rows, dim, spec))
     qspec = SynthSpec(seed=seed + 1, kind=2, noise=0.5, base_kind=1, base_seed=seed, base_n=sample_rows,
                       base_n_clusters=spec.n_clusters, base_noise=0.3)
@@ -51,20 +100,20 @@ def cpu_baseline(dim, k, target_rows, seed, budget_s=12.0):
         done += 1
     dt = time.perf_counter() - t0
     qps_sample = done / dt
-    # numpy/BLAS brute force on the same sample (SURVEY 8d baseline (a))
     t1 = time.perf_counter()
     reps = 0
     qn = oracle.normalize_rows(queries)
-    while reps < 64 and (time.perf_counter() - t1) < 5.0:
-        s = rows @ qn[reps]
+    while reps < 256 and (time.perf_counter() - t1) < 5.0:
+        s = rows @ qn[reps % 64]
         top = np.argpartition(-s, k)[:k]
         top = top[np.argsort(-s[top], kind="stable")]
         reps += 1
     np_qps = reps / (time.perf_counter() - t1)
     scale = sample_rows / target_rows
     return {"value": qps_sample * scale, "unit": "queries/s", "cores": int(oracle.lib().ora_num_threads()), "kind": "port",
-            "sample": f"{done} batch-1 queries over a {sample_rows}x{dim} fp32 sample of the corpus, exact top-{k}; "
+            "sample": f"{done} batch-1 queries over the first {sample_rows} rows (x{dim} fp32) of the corpus, exact top-{k}; "
                       f"QPS scaled by {sample_rows}/{target_rows} rows (linear scan)",
+            "qps_at_sample_rows": qps_sample, "numpy_sgemv_qps_at_sample_rows": np_qps,
             "numpy_sgemv_qps_scaled": np_qps * scale, "host_cpus": os.cpu_count(),
             "chroma_baseline": _chroma_note()}
 
@@ -77,97 +126,36 @@ def _chroma_note():
     return "chromadb importable: not timed by this script"
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--rows", type=int, default=10_000_000, help="total corpus rows (BASELINE: 10M)")
-    ap.add_argument("--dim", type=int, default=768)
-    ap.add_argument("--batch", type=int, default=1, help="queries per step (BASELINE: 1 and 1024)")
-    ap.add_argument("--k", type=int, default=10)
-    ap.add_argument("--kprime", type=int, default=40)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
-    ap.add_argument("--seed", type=int, default=1234)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--blocks-per-cu", type=int, default=0)
-    ap.add_argument("--nt", type=int, default=-1)
-    ap.add_argument("--mfma-variant", type=int, default=0)
-    ap.add_argument("--force-collective", action="store_true",
-                    help="diagnostic, 1 GPU: run the all-gather + merge exchange with a single-rank RCCL group")
-    ap.add_argument("--sync-exchange", action="store_true", help="diagnostic: wait for each batch's exchange (no overlap)")
-    ap.add_argument("--mfma-min-b", type=int, default=0, help="diagnostic: smallest batch sent to the MFMA path")
-    ap.add_argument("--clusters", type=int, default=0, help="synthetic clusters (default sqrt(rows))")
-    ap.add_argument("--time-every", type=int, default=4, help="HIP-event timing of the kernel on every Nth step (an event record idles the queue ~6 us)")
-    ap.add_argument("--two-phase", action="store_true", help="diagnostic: the merge/rerank of a batch moves to the exchange's side stream")
-    ap.add_argument("--no-skip-sample", action="store_true", help="diagnostic: the last MFMA pass re-multiplies the sampled tiles")
-    ap.add_argument("--mfma-split", type=int, default=0, help="diagnostic: mfma_split_x1000 option")
-    ap.add_argument("--ablate", type=int, default=0, help="diagnostic: MFMA kernel ablation bits (results invalid)")
-    args = ap.parse_args()
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the engine has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=device)
-    elif args.force_collective:
-        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29631", rank=0, world_size=1, device_id=device)
-
+def measure(sh, args, b, steps, warmup, qspec, device, world, n_local):
+    """Time `steps` steps of batch b (after `warmup` untimed ones) -> result block with its roofline."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    n, dim, k = args.rows, args.dim, args.k
     kp = args.kprime if args.dtype == "bf16" else 0
-    n, dim, b, k = args.rows, args.dim, args.batch, args.k
-    spec = SynthSpec(seed=args.seed, kind=1, n_clusters=args.clusters or max(1, int(np.sqrt(n))), noise=0.3)   # clustered (SURVEY 8d ii)
-    qspec = SynthSpec(seed=args.seed + 1, kind=2, noise=0.5, base_kind=1, base_seed=args.seed, base_n=n,
-                      base_n_clusters=spec.n_clusters, base_noise=0.3)
-
-    t_build = time.perf_counter()
-    sh = ShardedIndex(dim, args.dtype, True, device=device, force_collective=args.force_collective, two_phase=args.two_phase)
-    sh.add_synth_partition(n, spec)
-    lo, hi = shard_range(n, rank, world)
-    n_local = hi - lo
-    if args.blocks_per_cu:
-        sh.local.set_option("scan_blocks_per_cu", args.blocks_per_cu)
-    if args.mfma_variant:
-        sh.local.set_option("mfma_variant", args.mfma_variant)
-    if args.ablate:
-        sh.local.set_option("mfma_ablate", args.ablate)
-    if args.no_skip_sample:
-        sh.local.set_option("mfma_skip_sample", 0)
-    if args.mfma_split:
-        sh.local.set_option("mfma_split_x1000", args.mfma_split)
-    if args.mfma_min_b:
-        sh.local.set_option("batch_mfma_min_b", args.mfma_min_b)
-    if args.nt >= 0:
-        sh.local.set_option("scan_nt_loads", args.nt)
     # a pool of distinct query batches, resident in HBM
     n_sets = 16 if b > 1 else 64
     qpool = torch.empty((n_sets, b, dim), dtype=torch.float32, device=device)
     for s_ in range(n_sets):
         sh.local.synth_rows_device(qpool[s_].data_ptr(), s_ * b, b, qspec, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
-    t_build = time.perf_counter() - t_build
 
     def step(i):
         # throughput mode: the exchange of batch i (side stream) overlaps the scan of batch i+1;
         # every batch's exchange and merge still complete inside the timed region (device sync)
         return sh.search(qpool[i % n_sets], k, kp, wait=args.sync_exchange)
 
-    for i in range(args.warmup):
+    for i in range(warmup):
         step(i)
     torch.cuda.synchronize()
-    sh.local.set_option("timing_ring", max(1, min(args.steps, 65536)))
+    sh.local.set_option("timing_ring", max(1, min(steps, 65536)))
     sh.local.set_option("timing_every", max(1, args.time_every))
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        idx, dd = step(i)
+    for i in range(steps):
+        step(i)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -177,7 +165,7 @@ def main():
     sh.local.set_option("timing_every", 1)
     # outside the timed region: per-call latency with a sync after every call (median and p99)
     lat = []
-    for i in range(min(args.steps, 100)):
+    for i in range(min(steps, 100)):
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         step(i)
@@ -191,7 +179,7 @@ def main():
 
     # sanity inside the bench: planted neighbour of the last batch is rank 1 and results ascend
     # (a fresh call: the tensors the timed loop returned are ring buffers the latency loop has reused since)
-    last = (args.steps - 1) % n_sets
+    last = (steps - 1) % n_sets
     idx, dd = sh.search(qpool[last], k, kp)
     torch.cuda.synchronize()
     idx_h, dist_h = idx.cpu().numpy(), dd.cpu().numpy()
@@ -199,64 +187,134 @@ def main():
     src = np.array([query_source_row(qspec, last * b + j) for j in range(min(b, 8))])
     planted_ok = bool(np.array_equal(idx_h[: len(src), 0], src)) and bool(np.all(np.diff(dist_h, axis=1) >= 0))
 
-    if rank == 0:
-        esz = 2 if args.dtype == "bf16" else 4
-        mfma = b >= (args.mfma_min_b or 3) and args.dtype == "bf16"   # the engine's cost model agrees at 10M rows (vdb_api.hip)
-        scan_ms = tstats["scan_ms_sum"] / max(tstats["n"], 1)
-        if mfma:
-            alg = 2.0 * b * n_local * dim
-            roof = {"bound": "mfma", "achieved": alg / (scan_ms * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s"}
-            # operand bytes staged through LDS per batch: the path that actually binds the kernel
-            bn = 256 if 2 * (((b + 255) // 256) * 256) <= 3 * (((b + 127) // 128) * 128) else 128   # vdb_api.hip: mfma_search
-            b_pad = ((b + bn - 1) // bn) * bn
-            roof["lds_staged_bytes"] = float(n_local) * dim * esz * b_pad * (1.0 / bn + 1.0 / 256)
-            roof["lds_staging_TBps"] = roof["lds_staged_bytes"] / (scan_ms * 1e-3) / 1e12
+    esz = 2 if args.dtype == "bf16" else 4
+    path = sh.local.get_stat("last_path")            # 0 = GEMV scan, 4/5 = MFMA pass kernels, 6 = streaming MFMA kernel
+    scan_ms = tstats["scan_ms_sum"] / max(tstats["n"], 1)
+    kernel = {0: "scan_topk_kernel", 4: "scan_mfma_ws_kernel<1> + sample passes", 5: "scan_mfma_wide_kernel<1> + sample passes",
+              6: "scan_stream_mfma_kernel<1> + sample passes"}.get(path, f"path {path}")
+    if path in (4, 5):
+        alg = 2.0 * b * n_local * dim
+        roof = {"bound": "mfma", "achieved": alg / (scan_ms * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s"}
+        # operand bytes staged through LDS per batch: the path that actually binds the kernel
+        bn = 256 if path == 5 else 128
+        b_pad = ((b + bn - 1) // bn) * bn
+        roof["lds_staged_bytes"] = float(n_local) * dim * esz * b_pad * (1.0 / bn + 1.0 / 256)
+        roof["lds_staging_TBps"] = roof["lds_staged_bytes"] / (scan_ms * 1e-3) / 1e12
+    else:
+        alg = float(n_local) * dim * esz * sh.local.get_stat("last_corpus_passes")   # bytes per corpus pass x passes of the batch
+        roof = {"bound": "hbm", "achieved": alg / (scan_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "corpus_passes_per_batch": sh.local.get_stat("last_corpus_passes")}
+    roof["frac"] = roof["achieved"] / roof["peak"]
+    # the same ceilings as measured on this device (streaming read of the store in the scan's own launch shape;
+    # bare bf16 MFMA loop)
+    try:
+        if roof["bound"] == "mfma":
+            roof["measured_peak"] = sh.local.get_stat("probe_mfma_bf16_gflops") / 1e3
         else:
-            alg = float(n_local) * dim * esz           # one corpus pass per launch
-            roof = {"bound": "hbm", "achieved": alg / (scan_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s"}
-        roof["frac"] = roof["achieved"] / roof["peak"]
-        # the same ceilings as measured on this device (streaming read of the store; bare bf16 MFMA loop)
-        try:
-            if mfma:
-                roof["measured_peak"] = sh.local.get_stat("probe_mfma_bf16_gflops") / 1e3
-            else:
-                roof["measured_peak"] = sh.local.get_stat("probe_hbm_read_mbps") / 1e3
-            roof["frac_of_measured_peak"] = roof["achieved"] / roof["measured_peak"] if roof["measured_peak"] else None
-        except RuntimeError:
-            roof["measured_peak"] = None
-        # HBM bytes per launch from a separate rocprofv3 --pmc FETCH_SIZE pass of this same command
-        # (profiles/r01_pmc_traffic.json; gfx950 FETCH_SIZE correction applied there)
-        roof["traffic"] = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-                t = json.load(f)["workloads"].get(f"{n}x{dim} {args.dtype} batch {b}")
-            if t and world == 1:
-                roof["traffic"] = t["traffic_bytes"]
-                roof["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, separate pass)"
-        except (OSError, KeyError, ValueError):
-            pass
-        wide = mfma and 2 * (((b + 255) // 256) * 256) <= 3 * (((b + 127) // 128) * 128)
-        roof["kernel"] = ("scan_mfma_wide_kernel<1> + sample passes" if wide else "scan_mfma_ws_kernel<1> + sample passes") if mfma else "scan_topk_kernel"
-        roof["kernel_avg_ms"] = scan_ms
-        roof["kernel_timing"] = f"HIP events around the kernel on every {max(1, args.time_every)}th step of the timed region ({tstats['n']} samples)"
-        roof["merge_rerank_avg_ms"] = tstats["merge_ms_sum"] / max(tstats["n"], 1)
+            roof["measured_peak"] = sh.local.get_stat("probe_hbm_read_mbps") / 1e3
+        roof["frac_of_measured_peak"] = roof["achieved"] / roof["measured_peak"] if roof["measured_peak"] else None
+    except RuntimeError:
+        roof["measured_peak"] = None
+    # HBM bytes per launch: only a rocprofv3 --pmc FETCH_SIZE pass can tell, and this invocation is not one
+    # (profiles/r02_pmc_traffic.json holds the separate pass of this same command)
+    roof["traffic"] = None
+    roof["kernel"] = kernel
+    roof["kernel_avg_ms"] = scan_ms
+    roof["kernel_timing"] = f"HIP events around the scan phase on every {max(1, args.time_every)}th step of the timed region ({tstats['n']} samples)"
+    roof["merge_rerank_avg_ms"] = tstats["merge_ms_sum"] / max(tstats["n"], 1)
+    del qpool
+    return {
+        "value": steps * b / elapsed, "unit": "queries/s", "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
+        "batch": b, "roofline": roof,
+        "checks": {"planted_neighbour_first_and_ascending": planted_ok,
+                   "measured_peak_is_a_ceiling": (roof.get("frac_of_measured_peak") or 0) <= 1.02,
+                   "mfma_overflow_fallback": sh.local.get_stat("mfma_last_overflow"),
+                   "mfma_hits_per_query": sh.local.get_stat("mfma_last_hits") / b,
+                   **({"prof": [sh.local.get_stat("mfma_prof_" + c) for c in "abcd"]} if args.ablate & 8 else {})},
+        "sync_latency_ms": {"median": float(np.median(lat)), "p99": float(lat[min(len(lat) - 1, int(0.99 * len(lat)))]), "calls": len(lat)},
+    }
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)                      # does not return
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from vectordb_amd import SynthSpec
+    from vectordb_amd.distributed import ShardedIndex, shard_range
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the engine has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+    elif args.force_collective:
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29631", rank=0, world_size=1, device_id=device)
+
+    kp = args.kprime if args.dtype == "bf16" else 0
+    n, dim, k = args.rows, args.dim, args.k
+    spec = SynthSpec(seed=args.seed, kind=1, n_clusters=args.clusters or max(1, int(np.sqrt(n))), noise=0.3)   # clustered (SURVEY 8d ii)
+    qspec = SynthSpec(seed=args.seed + 1, kind=2, noise=0.5, base_kind=1, base_seed=args.seed, base_n=n,
+                      base_n_clusters=spec.n_clusters, base_noise=0.3)
+
+    t_build = time.perf_counter()
+    sh = ShardedIndex(dim, args.dtype, True, device=device, force_collective=args.force_collective, two_phase=args.two_phase)
+    sh.add_synth_partition(n, spec)
+    lo, hi = shard_range(n, rank, world)
+    n_local = hi - lo
+    if args.blocks_per_cu:
+        sh.local.set_option("scan_blocks_per_cu", args.blocks_per_cu)
+    if args.ablate:
+        sh.local.set_option("mfma_ablate", args.ablate)
+    if args.no_skip_sample:
+        sh.local.set_option("mfma_skip_sample", 0)
+    if args.mfma_split:
+        sh.local.set_option("mfma_split_x1000", args.mfma_split)
+    if args.mfma_min_b:
+        sh.local.set_option("batch_mfma_min_b", args.mfma_min_b)
+    if args.nt >= 0:
+        sh.local.set_option("scan_nt_loads", args.nt)
+    for ov in args.option:
+        name, _, val = ov.partition("=")
+        sh.local.set_option(name, int(val))
+    torch.cuda.synchronize()
+    t_build = time.perf_counter() - t_build
+
+    head = measure(sh, args, args.batch, args.steps, args.warmup, qspec, device, world, n_local)
+    second = None
+    if args.batch2 and args.batch2 != args.batch and args.dtype == "bf16":
+        second = measure(sh, args, args.batch2, max(1, min(args.steps, args.steps2)), max(1, min(args.warmup, 3)), qspec, device, world, n_local)
+
+    if rank == 0:
+        def workload(b):
+            return (f"{n}x{dim} {args.dtype} clustered synthetic corpus row-sharded over {world} GPU(s), "
+                    f"batch {b}, exact cosine top-{k}" + (f", k'={kp} fp32 rerank" if kp else ""))
         out = {
-            "metric": f"QPS @k={k}, {n // 1_000_000}Mx{dim} corpus, batch {b}",
-            "value": args.steps * b / elapsed, "unit": "queries/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "metric": f"QPS @k={k}, {n // 1_000_000}Mx{dim} corpus, batch {args.batch}",
+            "value": head["value"], "unit": "queries/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"{n}x{dim} {args.dtype} clustered synthetic corpus row-sharded over {world} GPU(s), "
-                                   f"batch {b}, exact cosine top-{k}" + (f", k'={kp} fp32 rerank" if kp else ""),
-                       "rows": n, "dim": dim, "batch": b, "k": k, "kprime": kp, "rows_per_gpu": n_local,
+            "config": {"workload": workload(args.batch),
+                       "rows": n, "dim": dim, "batch": args.batch, "k": k, "kprime": kp, "rows_per_gpu": n_local,
                        "parallelism": f"row-shard x{world} + all-gather merge" if world > 1 else "single GPU"},
-            "roofline": roof,
-            "checks": {"planted_neighbour_first_and_ascending": planted_ok,
-                       "mfma_overflow_fallback": sh.local.get_stat("mfma_last_overflow"),
-                       "mfma_hits_per_query": sh.local.get_stat("mfma_last_hits") / b,
-                       **({"prof": [sh.local.get_stat("mfma_prof_" + c) for c in "abcd"]} if args.ablate & 8 else {})},
-            "sync_latency_ms": {"median": float(np.median(lat)), "p99": float(lat[min(len(lat) - 1, int(0.99 * len(lat)))]), "calls": len(lat)},
+            "roofline": head["roofline"],
+            "checks": head["checks"],
+            "sync_latency_ms": head["sync_latency_ms"],
             "build_s": t_build,
         }
+        if second is not None:
+            second["metric"] = f"QPS @k={k}, {n // 1_000_000}Mx{dim} corpus, batch {args.batch2}"
+            second["workload"] = workload(args.batch2)
+            out[f"batch{args.batch2}"] = second
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dim, k, n, args.seed)
         print(json.dumps(out), flush=True)

@@ -72,6 +72,20 @@ typedef struct vdb_synth_spec {
  * keep_f32_for_rerank: with VDB_BF16, also keep fp32 rows for the rerank. */
 int vdb_create(vdb_t** out, int dim, int dtype, int keep_f32_for_rerank, int device_id);
 
+/* The same store ROW-SHARDED over the GPUs of one node, inside one process and one host thread (SURVEY.md 8b/8e;
+ * the reference is single-process, src/vectordb.py:259-264 — there is nothing to cite beyond the same call sites as
+ * vdb_create).  The handle routes every call to one child store per entry of device_ids (an id may repeat: several
+ * shards on one GPU).  vdb_reserve(h, total_rows) must come first: it fixes the partition — shard s owns global rows
+ * [s*per, (s+1)*per), per = ceil(total/n_devices) rounded up to 256, the last shard also any rows beyond the total —
+ * and row indices stay insertion order, so a sharded handle returns bit for bit what a single store of the same
+ * rows returns.  A search runs every shard's scan (+ shard-local fp32 rerank) concurrently on its own device and
+ * stream; each shard's finish kernel stores its k results straight into shard 0's gather buffer (over xGMI when peer
+ * access is available, a peer copy otherwise) and one merge kernel on shard 0 ranks the n_devices lists.  No host
+ * synchronisation inside vdb_search_dev; queries and outputs of the *_dev calls live on shard 0's device.
+ * Served on a sharded handle: reserve, add, add_synth, count, search, search_dev, fetch, save, last_timing,
+ * timing_stats, set_option (applied to every shard), get_stat.  Everything else returns VDB_ERR_STATE. */
+int vdb_create_sharded(vdb_t** out, int dim, int dtype, int keep_f32_for_rerank, const int* device_ids, int n_devices);
+
 /* Replaces client.delete_collection(name) for the vector segment
  * (src/vectordb.py:180). */
 void vdb_destroy(vdb_t* h);
@@ -110,7 +124,11 @@ int vdb_count(vdb_t* h, int64_t* n);
  * normalised).  rerank_kprime: 0 = no rerank; otherwise (bf16 store with fp32
  * copy) the scan keeps k' >= k candidates that are re-scored in fp32
  * (the GPU analogue of src/vectordb.py:282-314).  Outputs: b x k, padded with
- * idx -1 / dist +inf when fewer than k rows exist. */
+ * idx -1 / dist +inf when fewer than k rows exist.
+ * Precision: an fp32 store, and a bf16 store with a rerank, return fp32 cosines of the stored fp32 rows whatever the
+ * batch size.  A bf16 store searched WITHOUT a rerank returns the exact top-k of <fp32 query, bf16 row> scores; it
+ * always runs on the GEMV scan (the batched MFMA kernels round the queries to bf16 as well, which only a rerank
+ * repairs), so its result does not depend on the batch size either. */
 int vdb_search(vdb_t* h, const float* queries_host, int b, int k, int rerank_kprime,
                int64_t* out_idx_host, float* out_dist_host);
 
@@ -127,7 +145,10 @@ int vdb_search_dev(vdb_t* h, const float* queries_dev, int b, int k, int rerank_
  * event), and `slot` (0 or 1) names one of two workspace sets, so that phase 2 of batch i overlaps phase 1 of
  * batch i+1.  A slot holds one pending scan.  Only batches that run as ONE scan round split: 1..64 queries on
  * the GEMV scan; otherwise vdb_search_scan_dev returns VDB_ERR_STATE and does nothing (use vdb_search_dev).
- * Same results as vdb_search_dev.  No counterpart in the reference (its queries are synchronous, one at a time). */
+ * Same results as vdb_search_dev.  No counterpart in the reference (its queries are synchronous, one at a time).
+ * While a scan is pending in either slot, every other search entry point of the handle (they share slot 0's
+ * workspaces), vdb_selfjoin and the "timing_ring" option return VDB_ERR_STATE; a second scan into a slot that is
+ * still pending does too. */
 int vdb_search_scan_dev(vdb_t* h, const float* queries_dev, int b, int k, int rerank_kprime, int slot, void* stream);
 int vdb_search_finish_dev(vdb_t* h, int slot, int64_t* out_idx_dev, float* out_dist_dev, void* stream);
 
@@ -179,6 +200,11 @@ int vdb_fetch(vdb_t* h, const int64_t* idx_host, int64_t n, float* out_rows_host
  * src/vectordb.py:149): flat file `<dir>/vectors.vdb`. */
 int vdb_save(vdb_t* h, const char* dir);
 int vdb_load(vdb_t** out, const char* dir, int dtype, int keep_f32_for_rerank, int device_id);
+/* Reopen a saved store row-sharded (vdb_create_sharded's partition of the file's row count).  The file format is
+ * the same whichever kind of handle wrote it; vdb_save writes to a temporary name and renames it into place, and
+ * vdb_load* reject a header whose row count, dimension or dtype is out of range or disagrees with the file's
+ * length (VDB_ERR_IO). */
+int vdb_load_sharded(vdb_t** out, const char* dir, int dtype, int keep_f32_for_rerank, const int* device_ids, int n_devices);
 
 /* ---- measurement ------------------------------------------------------- */
 
@@ -193,16 +219,20 @@ int vdb_last_timing(vdb_t* h, float* scan_ms, float* merge_ms, double* bytes_str
  * region without synchronising between steps.  reset != 0 restarts the count. */
 int vdb_timing_stats(vdb_t* h, int64_t* n_searches, double* scan_ms_sum, double* merge_ms_sum, int reset);
 
-/* Tuning knobs: "timing_ring", "timing_every" (record the timing events on every Nth search only; default 1), "scan_blocks_per_cu", "scan_nt_loads", "batch_mfma_min_b" (default 3),
+/* Tuning knobs: "timing_ring", "timing_every" (record the timing events on every Nth search only; default 1), "scan_blocks_per_cu", "scan_nt_loads", "batch_mfma_min_b" (default 2),
  * "mfma_cost_model" (default 1: a batch takes the MFMA path only where it is faster than ceil(b/4) GEMV passes;
- * 0: whenever it is supported), "mfma_variant", "mfma_append_cap", "mfma_split_x1000" (where the sample pass sits between the dense sample and
+ * 0: whenever it is supported), "mfma_variant" (4: 256x128 tiles only; 5: + 256x256 tiles; 6, default: + the streaming
+ * kernel for <= 64 queries), "stream_nt_loads", "mfma_append_cap", "mfma_split_x1000" (where the sample pass sits between the dense sample and
  * the full pass; 500 = geometric mean, measured best), "mfma_force_fallback".
  * Unknown names return VDB_ERR_ARG. */
 int vdb_set_option(vdb_t* h, const char* name, int64_t value);
 
 /* Read-only counters/diagnostics (synchronises the device): "mfma_last_overflow" (1 when the
  * last batched search overflowed its candidate buffers and ran the exact list kernel),
- * "rows", "capacity_rows", "mfma_last_hits", "mfma_last_skipped_tiles" (tiles the final pass of the last
+ * "rows", "capacity_rows", "n_shards", "rows_per_shard" and "p2p_direct_shards" (sharded handles),
+ * "last_path" (kernel family of the last search: 0 = GEMV scan, 4 / 5 = tiled MFMA kernels, 6 = streaming MFMA kernel),
+ * "last_corpus_passes" (corpus passes of the last search: the roofline's algorithmic bytes = passes x rows x row bytes),
+ * "mfma_last_hits", "mfma_last_skipped_tiles" (tiles the final pass of the last
  * batched search left out because the sample pass had multiplied them); measured ceilings of this device (a few ms
  * each): "probe_hbm_read_mbps" (streams the store's own rows, needs >= 64 MiB of them) and
  * "probe_mfma_bf16_gflops" (bare v_mfma_f32_32x32x16_bf16 loop).  Unknown names return VDB_ERR_ARG. */

@@ -201,6 +201,8 @@ struct vdb {
   float* rows;       /* normalised fp32 (dtype f32, or bf16 with keep_f32) */
   uint16_t* rows16;  /* bf16 bits (dtype bf16)                             */
   double last_bytes;
+  int n_shards;       /* > 0: made by vdb_create_sharded (a brute force has nothing to shard: one store, same answers) */
+  int reserved;       /* vdb_reserve has been called (a sharded handle insists on it before rows are added) */
   float* split_q[2];  /* queries of a pending two-phase search, per slot */
   int split_b[2], split_k[2], split_kp[2];
   char err[256];
@@ -223,6 +225,16 @@ int vdb_create(vdb_t** out, int dim, int dtype, int keep_f32, int device_id) {
   *out = h;
   return VDB_OK;
 }
+/* The oracle's answer does not depend on how the engine shards its rows: the sharded handle is the plain exact
+ * store (that IS the contract of vdb_create_sharded in include/vdb.h); only its calling rules are mirrored. */
+int vdb_create_sharded(vdb_t** out, int dim, int dtype, int keep_f32, const int* device_ids, int n_devices) {
+  if (!out) return fail(NULL, VDB_ERR_ARG, "vdb_create_sharded: out is NULL");
+  if (!device_ids || n_devices < 1 || n_devices > 64) return fail(NULL, VDB_ERR_ARG, "vdb_create_sharded: need 1..64 device ids");
+  int rc = vdb_create(out, dim, dtype, keep_f32, 0);
+  if (rc) return rc;
+  (*out)->n_shards = n_devices;
+  return VDB_OK;
+}
 void vdb_destroy(vdb_t* h) {
   if (!h) return;
   free(h->rows); free(h->rows16); free(h->split_q[0]); free(h->split_q[1]); free(h);
@@ -231,6 +243,7 @@ const char* vdb_last_error(vdb_t* h) { return h ? h->err : g_err; }
 
 int vdb_reserve(vdb_t* h, int64_t n_rows) {
   if (!h) return VDB_ERR_ARG;
+  h->reserved = 1;
   if (n_rows <= h->cap) return VDB_OK;
   if (h->keep_f32) {
     float* p = (float*)realloc(h->rows, sizeof(float) * (size_t)n_rows * h->dim);
@@ -255,6 +268,7 @@ int vdb_add(vdb_t* h, const float* rows, int64_t n) {
   if (!h) return VDB_ERR_ARG;
   if (n < 0 || (n > 0 && !rows)) return fail(h, VDB_ERR_ARG, "vdb_add: bad rows/n");
   if (n == 0) return VDB_OK;
+  if (h->n_shards && !h->reserved) return fail(h, VDB_ERR_STATE, "vdb_add: call vdb_reserve(total rows) on a sharded handle first (it fixes the row partition)");
   if (h->n + n > h->cap) {
     int64_t want = h->cap + h->cap / 2;
     if (want < h->n + n) want = h->n + n;
@@ -432,9 +446,10 @@ typedef struct { char magic[8]; int32_t dim; int32_t stored_dtype; int64_t n; in
 int vdb_save(vdb_t* h, const char* dir) {
   if (!h || !dir) return VDB_ERR_ARG;
   mkdir(dir, 0777);
-  char path[4096];
+  char path[4096], tmp[4200];
   snprintf(path, sizeof path, "%s/vectors.vdb", dir);
-  FILE* f = fopen(path, "wb");
+  snprintf(tmp, sizeof tmp, "%s.tmp", path);
+  FILE* f = fopen(tmp, "wb");
   if (!f) return fail(h, VDB_ERR_IO, "save: cannot open file for writing");
   vdb_file_header hd;
   memset(&hd, 0, sizeof hd);
@@ -444,6 +459,8 @@ int vdb_save(vdb_t* h, const char* dir) {
   size_t cnt = (size_t)h->n * h->dim;
   if (ok && cnt) ok = h->keep_f32 ? fwrite(h->rows, 4, cnt, f) == cnt : fwrite(h->rows16, 2, cnt, f) == cnt;
   fclose(f);
+  if (ok && rename(tmp, path) != 0) ok = 0;
+  if (!ok) remove(tmp);
   return ok ? VDB_OK : fail(h, VDB_ERR_IO, "save: short write");
 }
 
@@ -455,6 +472,18 @@ int vdb_load(vdb_t** out, const char* dir, int dtype, int keep_f32, int device_i
   if (!f) return fail(NULL, VDB_ERR_IO, "load: cannot open vectors.vdb");
   vdb_file_header hd;
   if (fread(&hd, sizeof hd, 1, f) != 1 || memcmp(hd.magic, "VDBFLAT1", 8) != 0) { fclose(f); return fail(NULL, VDB_ERR_IO, "load: bad header"); }
+  if (hd.dim <= 0 || hd.dim > 32768 || (hd.stored_dtype != VDB_F32 && hd.stored_dtype != VDB_BF16) || hd.n < 0) {
+    fclose(f);
+    return fail(NULL, VDB_ERR_IO, "load: bad header (dim, dtype or row count out of range)");
+  }
+  {
+    struct stat sb;
+    int64_t want = (int64_t)sizeof hd + hd.n * (int64_t)hd.dim * (hd.stored_dtype == VDB_F32 ? 4 : 2);
+    if (fstat(fileno(f), &sb) != 0 || (int64_t)sb.st_size != want) {
+      fclose(f);
+      return fail(NULL, VDB_ERR_IO, "load: vectors.vdb is truncated or its header disagrees with its length");
+    }
+  }
   if (hd.stored_dtype == VDB_BF16 && (dtype == VDB_F32 || keep_f32)) { fclose(f); return fail(NULL, VDB_ERR_STATE, "load: file holds bf16 rows only; cannot rebuild fp32 rows"); }
   vdb_t* h;
   int rc = vdb_create(&h, hd.dim, dtype, keep_f32, device_id);
@@ -480,6 +509,14 @@ int vdb_load(vdb_t** out, const char* dir, int dtype, int keep_f32, int device_i
   return VDB_OK;
 }
 
+int vdb_load_sharded(vdb_t** out, const char* dir, int dtype, int keep_f32, const int* device_ids, int n_devices) {
+  if (!device_ids || n_devices < 1 || n_devices > 64) return fail(NULL, VDB_ERR_ARG, "vdb_load_sharded: need 1..64 device ids");
+  int rc = vdb_load(out, dir, dtype, keep_f32, 0);
+  if (rc) return rc;
+  (*out)->n_shards = n_devices; (*out)->reserved = 1;
+  return VDB_OK;
+}
+
 int vdb_last_timing(vdb_t* h, float* scan_ms, float* merge_ms, double* bytes) {
   if (!h) return VDB_ERR_ARG;
   if (scan_ms) *scan_ms = 0.f;
@@ -491,6 +528,9 @@ int vdb_get_stat(vdb_t* h, const char* name, int64_t* value) {
   if (!h || !name || !value) return VDB_ERR_ARG;
   if (!strcmp(name, "rows")) { *value = h->n; return VDB_OK; }
   if (!strcmp(name, "capacity_rows")) { *value = h->cap; return VDB_OK; }
+  if (!strcmp(name, "n_shards")) { *value = h->n_shards ? h->n_shards : 1; return VDB_OK; }
+  if (!strcmp(name, "last_path") || !strcmp(name, "p2p_direct_shards")) { *value = 0; return VDB_OK; }
+  if (!strcmp(name, "last_corpus_passes")) { *value = 1; return VDB_OK; }
   if (!strcmp(name, "mfma_last_overflow") || !strcmp(name, "mfma_last_hits") || !strcmp(name, "mfma_last_skipped_tiles")) { *value = 0; return VDB_OK; }
   return fail(h, VDB_ERR_ARG, "get_stat: unknown stat");
 }
@@ -505,7 +545,7 @@ int vdb_timing_stats(vdb_t* h, int64_t* n, double* a, double* b, int reset) {
 int vdb_set_option(vdb_t* h, const char* name, int64_t value) {
   (void)value;
   if (!h || !name) return VDB_ERR_ARG;
-  if (!strcmp(name, "mfma_variant") || !strcmp(name, "mfma_cost_model") || !strcmp(name, "mfma_force_fallback") || !strcmp(name, "mfma_append_cap") || !strcmp(name, "mfma_ablate") || !strcmp(name, "timing_ring") || !strcmp(name, "timing_every") || !strcmp(name, "mfma_split_x1000") || !strcmp(name, "mfma_skip_sample") || !strcmp(name, "scan_blocks_per_cu") || !strcmp(name, "scan_nt_loads") || !strcmp(name, "batch_mfma_min_b")) return VDB_OK;
+  if (!strcmp(name, "mfma_variant") || !strcmp(name, "mfma_cost_model") || !strcmp(name, "mfma_force_fallback") || !strcmp(name, "mfma_append_cap") || !strcmp(name, "mfma_ablate") || !strcmp(name, "timing_ring") || !strcmp(name, "timing_every") || !strcmp(name, "mfma_split_x1000") || !strcmp(name, "mfma_skip_sample") || !strcmp(name, "scan_blocks_per_cu") || !strcmp(name, "scan_nt_loads") || !strcmp(name, "batch_mfma_min_b") || !strcmp(name, "stream_nt_loads")) return VDB_OK;
   return fail(h, VDB_ERR_ARG, "set_option: unknown option");
 }
 

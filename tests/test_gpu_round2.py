@@ -1,0 +1,302 @@
+"""GPU suite, round 2: the streaming MFMA kernel (2..64 queries), the row-sharded handle behind the C ABI
+(vdb_create_sharded, several shards on the one GPU of the test box), store-file validation and the batched
+path's query chunking.  Everything goes through the C ABI and is checked against the CPU oracle or against the
+single-store answer, bit for bit where the contract says so."""
+import ctypes as C
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from vectordb_amd import FlatIndex, SynthSpec
+from vectordb_amd._capi import VdbError
+from tests.util import check_topk
+
+pytestmark = pytest.mark.gpu
+
+
+def _qn(oracle_mod, queries):
+    return oracle_mod.normalize_rows(np.ascontiguousarray(queries, np.float32))
+
+
+@pytest.fixture(scope="module")
+def corpus33k(oracle_mod):
+    n, dim = 33003, 768          # ragged against 16-row wave tiles, 256-row protocol tiles and the dense sample
+    spec = SynthSpec(seed=4321, kind=1, n_clusters=181, noise=0.3)
+    qspec = SynthSpec(seed=77, kind=2, noise=0.5, base_kind=1, base_seed=4321, base_n=n, base_n_clusters=181, base_noise=0.3)
+    rows = oracle_mod.normalize_rows(oracle_mod.synth_rows(0, n, dim, spec))
+    queries = oracle_mod.synth_rows(0, 64, dim, qspec)
+    return n, dim, spec, rows, queries
+
+
+@pytest.mark.parametrize("nt", [0, 1])
+def test_stream_kernel_against_oracle(hip_lib, oracle_mod, corpus33k, nt):
+    """Every query-block count of the streaming kernel (1, 2, 4 blocks of 16) with ragged batches, plain and
+    non-temporal loads; the path taken is asserted, not assumed."""
+    n, dim, spec, rows, queries = corpus33k
+    ix = FlatIndex(dim, "bf16", True)
+    ix.set_option("mfma_cost_model", 0)
+    ix.set_option("stream_nt_loads", nt)
+    ix.add_synth(0, n, spec)
+    qn = _qn(oracle_mod, queries)
+    for b in (2, 3, 16, 17, 32, 33, 64):
+        for k, kp in ((10, 40), (1, 8), (30, 64)):
+            idx, dist = ix.search(queries[:b], k, kp)
+            assert ix.get_stat("last_path") == 6, "the streaming kernel must have served this batch"
+            assert ix.get_stat("mfma_last_overflow") == 0
+            r_idx, r_dist, r_sc = oracle_mod.exact_topk(rows, queries[:b], k)
+            check_topk(idx, dist, r_idx, r_dist, r_sc, rows, qn[:b], what=f"stream b={b} k={k} nt={nt}")
+    # the batch-1 GEMV answer is the same answer
+    i64, d64 = ix.search(queries, 10, 40)
+    for q in (0, 31, 63):
+        i1, d1 = ix.search(queries[q:q + 1], 10, 40)
+        assert ix.get_stat("last_path") == 0
+        assert np.array_equal(i1[0], i64[q]) and np.array_equal(d1[0], d64[q])
+    ix.close()
+
+
+def test_stream_kernel_multi_pass_and_selfjoin(hip_lib, oracle_mod):
+    """Enough tiles that the protocol runs its sample pass and a final pass that skips the sampled tiles, several
+    tiles per wave, and the self-join exclusion (a 64-row block of rows-as-queries)."""
+    n, dim = 300_007, 768
+    spec = SynthSpec(seed=909, kind=1, n_clusters=547, noise=0.3)
+    rows = oracle_mod.normalize_rows(oracle_mod.synth_rows(0, n, dim, spec))
+    qspec = SynthSpec(seed=910, kind=2, noise=0.5, base_kind=1, base_seed=909, base_n=n, base_n_clusters=547, base_noise=0.3)
+    queries = oracle_mod.synth_rows(0, 40, dim, qspec)
+    ix = FlatIndex(dim, "bf16", True)
+    ix.set_option("mfma_cost_model", 0)
+    ix.add_synth(0, n, spec)
+    idx, dist = ix.search(queries, 10, 40)
+    assert ix.get_stat("last_path") == 6 and ix.get_stat("mfma_last_overflow") == 0
+    assert ix.get_stat("mfma_last_skipped_tiles") > 0
+    r_idx, r_dist, r_sc = oracle_mod.exact_topk(rows, queries, 10)
+    check_topk(idx, dist, r_idx, r_dist, r_sc, rows, _qn(oracle_mod, queries), what="stream 300k")
+    # same answer with the tiled kernel and with the last pass re-multiplying the sampled tiles
+    ix.set_option("mfma_variant", 5)
+    i5, d5 = ix.search(queries, 10, 40)
+    assert ix.get_stat("last_path") == 4
+    assert np.array_equal(i5, idx) and np.array_equal(d5, dist)
+    ix.set_option("mfma_variant", 6)
+    ix.set_option("mfma_skip_sample", 0)
+    i6, d6 = ix.search(queries, 10, 40)
+    assert np.array_equal(i6, idx) and np.array_equal(d6, dist)
+    ix.set_option("mfma_skip_sample", 1)
+    sj_idx, sj_dist = ix.selfjoin(5, exclude_self=True, rerank_kprime=40, q_row0=299_950, q_n=57)
+    assert ix.get_stat("last_path") == 6
+    assert not np.any(sj_idx == (299_950 + np.arange(57))[:, None])
+    for j in (0, 30, 56):
+        masked = rows.copy()
+        masked[299_950 + j] = 0
+        q = rows[299_950 + j:299_951 + j]
+        m_idx, m_dist, m_sc = oracle_mod.exact_topk(masked, q, 5)
+        check_topk(sj_idx[j:j + 1], sj_dist[j:j + 1], m_idx, m_dist, m_sc, rows, q, what=f"stream selfjoin q{j}")
+    ix.close()
+
+
+def test_stream_kernel_overflow_fallback_and_bad_thresholds(hip_lib, oracle_mod, corpus33k):
+    """Tiny candidate buffers -> the device-side overflow flag routes through the exact list kernel; and queries
+    whose cosines are all <= 0 (non-positive thresholds take the float compare)."""
+    n, dim, spec, rows, queries = corpus33k
+    ix = FlatIndex(dim, "bf16", True)
+    ix.set_option("mfma_cost_model", 0)
+    ix.add_synth(0, n, spec)
+    base_i, base_d = ix.search(queries[:24], 10, 40)
+    ix.set_option("mfma_append_cap", 256)
+    i2, d2 = ix.search(queries[:24], 10, 40)
+    assert ix.get_stat("mfma_last_overflow") == 1
+    assert np.array_equal(i2, base_i) and np.array_equal(d2, base_d)
+    ix.set_option("mfma_append_cap", 16384)
+    neg = -np.abs(queries[:10])            # rows are centroid + noise around 0: mirror the query so that most cosines go negative
+    idx, dist = ix.search(neg, 10, 40)
+    r_idx, r_dist, r_sc = oracle_mod.exact_topk(rows, neg, 10)
+    check_topk(idx, dist, r_idx, r_dist, r_sc, rows, _qn(oracle_mod, neg), what="stream negative thresholds")
+    ix.close()
+
+
+def test_batched_path_chunks_large_batches(hip_lib, oracle_mod):
+    """More queries than one batched launch takes (4096): the engine chunks them; every chunk's answers equal the
+    answers of the same queries asked alone."""
+    n, dim, b = 20_000, 768, 4096 + 300
+    spec = SynthSpec(seed=31, kind=1, n_clusters=141, noise=0.3)
+    qspec = SynthSpec(seed=32, kind=2, noise=0.5, base_kind=1, base_seed=31, base_n=n, base_n_clusters=141, base_noise=0.3)
+    queries = oracle_mod.synth_rows(0, b, dim, qspec)
+    ix = FlatIndex(dim, "bf16", True)
+    ix.set_option("mfma_cost_model", 0)
+    ix.add_synth(0, n, spec)
+    idx, dist = ix.search(queries, 10, 40)
+    for lo, hi in ((0, 8), (4090, 4102), (b - 5, b)):
+        i1, d1 = ix.search(queries[lo:hi], 10, 40)
+        assert np.array_equal(i1, idx[lo:hi]) and np.array_equal(d1, dist[lo:hi])
+    rows = oracle_mod.normalize_rows(oracle_mod.synth_rows(0, n, dim, spec))
+    sel = np.r_[0:4, 4094:4098, b - 4:b]
+    r_idx, r_dist, r_sc = oracle_mod.exact_topk(rows, queries[sel], 10)
+    check_topk(idx[sel], dist[sel], r_idx, r_dist, r_sc, rows, _qn(oracle_mod, queries[sel]), what="chunked batch")
+    ix.close()
+
+
+@pytest.mark.parametrize("dtype,kp", [("f32", 0), ("bf16", 40)])
+@pytest.mark.parametrize("g", [1, 2, 3, 8])
+def test_sharded_handle_equals_single_store(hip_lib, oracle_mod, corpus33k, g, dtype, kp):
+    """vdb_create_sharded with g shards (all on the one GPU of this box): add through the router, search through
+    the router — bit-identical to the single store, and equal to the oracle."""
+    n, dim, spec, rows, queries = corpus33k
+    single = FlatIndex(dim, dtype, True)
+    single.add_synth(0, n, spec)
+    sh = FlatIndex(dim, dtype, True, devices=[0] * g)
+    with pytest.raises(VdbError):
+        sh.add_synth(0, 10, spec)            # the partition is not fixed yet
+    sh.reserve(n)
+    assert sh.get_stat("n_shards") == g and sh.get_stat("rows_per_shard") % 256 == 0
+    sh.add_synth(0, 20_000, spec)            # two appends that straddle shard boundaries
+    sh.add_synth(20_000, n - 20_000, spec)
+    assert sh.count() == n
+    assert sh.get_stat("p2p_direct_shards") == g
+    qn = _qn(oracle_mod, queries)
+    for b in (1, 4, 40):
+        for k in (1, 10, 30):
+            if kp and kp < k:
+                continue
+            i_s, d_s = single.search(queries[:b], k, kp)
+            i_g, d_g = sh.search(queries[:b], k, kp)
+            assert np.array_equal(i_g, i_s) and np.array_equal(d_g, d_s), f"g={g} b={b} k={k}"
+    r_idx, r_dist, r_sc = oracle_mod.exact_topk(rows, queries[:9], 10)
+    i_g, d_g = sh.search(queries[:9], 10, kp)
+    check_topk(i_g, d_g, r_idx, r_dist, r_sc, rows, qn[:9], what=f"sharded g={g} {dtype}")
+    # fetch routes global indices to their shards
+    pick = np.array([0, 1, sh.get_stat("rows_per_shard") - 1, sh.get_stat("rows_per_shard") % n, n - 1, 12345], np.int64)
+    assert np.array_equal(sh.fetch(pick), single.fetch(pick))
+    t = sh.last_timing()
+    assert t["scan_ms"] > 0 and t["bytes_streamed"] > 0
+    single.close()
+    sh.close()
+
+
+def test_sharded_host_rows_k_larger_than_a_shard_and_device_entry(hip_lib, oracle_mod):
+    """Rows added from host memory through the router; k larger than a shard's row count (shards pad with -1, the
+    merge ignores the padding); the device-pointer entry point with torch buffers."""
+    import torch
+    rng = np.random.default_rng(11)
+    n, dim = 700, 96
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    rows_n = oracle_mod.normalize_rows(rows)
+    queries = rows[[5, 300, 650]] + 0.05 * rng.standard_normal((3, dim)).astype(np.float32)
+    sh = FlatIndex(dim, "f32", devices=[0, 0, 0])
+    sh.reserve(n)                     # per = 256: shards hold 256 / 256 / 188 rows
+    sh.add(rows[:300]); sh.add(rows[300:])
+    assert sh.count() == n
+    for k in (10, 300, 1000):
+        idx, dist = sh.search(queries, k)
+        r_idx, r_dist, r_sc = oracle_mod.exact_topk(rows_n, queries, k)
+        check_topk(idx, dist, r_idx, r_dist, r_sc, rows_n, _qn(oracle_mod, queries), what=f"sharded host rows k={k}")
+    q_t = torch.from_numpy(queries).cuda()
+    oi = torch.empty((3, 10), dtype=torch.int64, device="cuda")
+    od = torch.empty((3, 10), dtype=torch.float32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(3):                # back-to-back calls reuse the gather buffer behind stream order only
+        sh.search_device(q_t.data_ptr(), 3, 10, 0, oi.data_ptr(), od.data_ptr(), st)
+    torch.cuda.synchronize()
+    idx, dist = sh.search(queries, 10)
+    assert np.array_equal(oi.cpu().numpy(), idx) and np.array_equal(od.cpu().numpy(), dist)
+    # rows beyond the reserved total go to the last shard and keep their global indices
+    extra = rng.standard_normal((100, dim)).astype(np.float32)
+    sh.add(extra)
+    all_n = oracle_mod.normalize_rows(np.concatenate([rows, extra]))
+    q2 = extra[[3, 77]]
+    idx, dist = sh.search(q2, 5)
+    r_idx, r_dist, r_sc = oracle_mod.exact_topk(all_n, q2, 5)
+    check_topk(idx, dist, r_idx, r_dist, r_sc, all_n, _qn(oracle_mod, q2), what="sharded overflow rows")
+    assert idx[0, 0] == n + 3 and idx[1, 0] == n + 77
+    # what a sharded handle does not serve says so
+    with pytest.raises(VdbError) as e:
+        sh.selfjoin(3)
+    assert e.value.code == -5
+    with pytest.raises(VdbError):
+        sh.search_masked(queries, 3, np.ones(sh.count(), bool))
+    sh.close()
+
+
+def test_sharded_save_load_roundtrip(hip_lib, oracle_mod, tmp_path, corpus33k):
+    """One file format whatever the handle: sharded -> single, single -> sharded, sharded -> sharded with another
+    shard count; searches agree bit for bit."""
+    n, dim, spec, rows, queries = corpus33k
+    a = FlatIndex(dim, "bf16", True, devices=[0, 0, 0])
+    a.reserve(n)
+    a.add_synth(0, n, spec)
+    ia, da = a.search(queries[:5], 10, 40)
+    a.save(str(tmp_path / "s3"))
+    a.close()
+    b = FlatIndex.load(str(tmp_path / "s3"), "bf16", True)
+    assert b.count() == n
+    ib, db = b.search(queries[:5], 10, 40)
+    assert np.array_equal(ia, ib) and np.array_equal(da, db)
+    b.save(str(tmp_path / "s1"))
+    b.close()
+    c = FlatIndex.load(str(tmp_path / "s1"), "bf16", True, devices=[0, 0])
+    assert c.count() == n and c.get_stat("n_shards") == 2
+    ic, dc = c.search(queries[:5], 10, 40)
+    assert np.array_equal(ia, ic) and np.array_equal(da, dc)
+    c.close()
+
+
+def test_store_file_validation(hip_lib, tmp_path):
+    """vdb_load rejects a truncated file and headers that lie (negative / huge row count, bad dim, bad dtype);
+    vdb_save leaves no temporary file behind."""
+    rng = np.random.default_rng(2)
+    ix = FlatIndex(32, "f32")
+    ix.add(rng.standard_normal((100, 32)).astype(np.float32))
+    d = tmp_path / "store"
+    ix.save(str(d))
+    ix.close()
+    assert sorted(os.listdir(d)) == ["vectors.vdb"]
+    good = (d / "vectors.vdb").read_bytes()
+    assert len(good) == 32 + 100 * 32 * 4
+    FlatIndex.load(str(d), "f32").close()
+
+    def corrupt(name, data):
+        dd = tmp_path / name
+        dd.mkdir()
+        (dd / "vectors.vdb").write_bytes(data)
+        with pytest.raises(VdbError) as e:
+            FlatIndex.load(str(dd), "f32")
+        assert e.value.code == -4, name      # VDB_ERR_IO
+        with pytest.raises(VdbError):
+            FlatIndex.load(str(dd), "f32", devices=[0, 0])
+
+    hdr = lambda dim, dt, n: b"VDBFLAT1" + struct.pack("<iiqq", dim, dt, n, 0)   # noqa: E731
+    corrupt("truncated", good[:-40])
+    corrupt("longer", good + b"\0" * 8)
+    corrupt("negative_n", hdr(32, 0, -5) + good[32:])
+    corrupt("huge_n", hdr(32, 0, 1 << 40) + good[32:])
+    corrupt("bad_dim", hdr(0, 0, 100) + good[32:])
+    corrupt("bad_dtype", hdr(32, 7, 100) + good[32:])
+    corrupt("bad_magic", b"VDBFLAT2" + good[8:])
+
+
+def test_pending_two_phase_scan_blocks_other_searches(hip_lib, oracle_mod):
+    """A scan pending in a slot owns the handle's workspaces: other searches, a second scan into the same slot and
+    a timing-ring resize say VDB_ERR_STATE instead of silently overwriting it; the finish then returns the right answer."""
+    import torch
+    n, dim = 5000, 768
+    spec = SynthSpec(seed=3, kind=0)
+    ix = FlatIndex(dim, "f32")
+    ix.add_synth(0, n, spec)
+    q = torch.from_numpy(oracle_mod.synth_rows(10, 2, dim, spec)).cuda()
+    oi = torch.empty((2, 5), dtype=torch.int64, device="cuda")
+    od = torch.empty((2, 5), dtype=torch.float32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    ref_i, ref_d = ix.search(q.cpu().numpy(), 5)
+    assert ix.search_scan_device(q.data_ptr(), 2, 5, 0, 0, st)
+    for call in (lambda: ix.search(q.cpu().numpy(), 5),
+                 lambda: ix.search_device(q.data_ptr(), 2, 5, 0, oi.data_ptr(), od.data_ptr(), st),
+                 lambda: ix.selfjoin(3, q_n=4),
+                 lambda: ix.set_option("timing_ring", 8),
+                 lambda: ix._chk(ix._lib.vdb_search_scan_dev(ix._h, q.data_ptr(), 2, 5, 0, 0, None))):
+        with pytest.raises(VdbError) as e:
+            call()
+        assert e.value.code == -5
+    ix.search_finish_device(0, oi.data_ptr(), od.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert np.array_equal(oi.cpu().numpy(), ref_i) and np.array_equal(od.cpu().numpy(), ref_d)
+    ix.search(q.cpu().numpy(), 5)          # and the handle is usable again
+    ix.close()

@@ -44,7 +44,9 @@ def test_collection_query_shape(tmp_path, oracle_lib):
     assert res["ids"][0][0] == "item_2" and abs(res["distances"][0][0]) < 1e-6
     assert res["distances"][0] == sorted(res["distances"][0])
     assert res["documents"][0] == [None] * 6
-    assert np.array_equal(np.asarray(res["embeddings"][0][0]), emb[2])   # embeddings come back as added
+    # embeddings come back as STORED: the L2-normalised row (what chromadb's cosine-space segment returns too;
+    # the reference's model emits unit vectors, so for it stored == added)
+    assert np.allclose(np.asarray(res["embeddings"][0][0]), emb[2] / np.linalg.norm(emb[2]), atol=1e-6)
     assert res["metadatas"][0][0]["product_description"] == "p2"
     only = col.query(query_embeddings=emb[:2].tolist(), n_results=2, include=["distances"])
     assert only["metadatas"] is None and len(only["ids"]) == 2
@@ -53,7 +55,7 @@ def test_collection_query_shape(tmp_path, oracle_lib):
     assert sorted(f["ids"][0]) == ["item_1", "item_3", "item_5"]
     # get(): flat lists, unknown ids dropped
     got = col.get(ids=["item_4", "nope"], include=["embeddings", "metadatas"])
-    assert got["ids"] == ["item_4"] and np.array_equal(np.asarray(got["embeddings"][0]), emb[4])
+    assert got["ids"] == ["item_4"] and np.allclose(np.asarray(got["embeddings"][0]), emb[4] / np.linalg.norm(emb[4]), atol=1e-6)
     assert col.get(ids=["nope"])["ids"] == []
     # re-adding existing ids is ignored; duplicate ids inside one call raise
     col.add(embeddings=emb[:2].tolist(), ids=["item_0", "item_1"])

@@ -14,10 +14,21 @@ Reproduces exactly the slice of the chromadb API the reference touches
         analysis/run_bidirectional_test.py:139; analysis/generate_best_usda_matches.py:196
   collection.get(ids=, include=)                        analysis/generate_best_usda_matches.py:185
 
-The vector segment (chromadb's HNSW index) is a FlatIndex on the GPU; ids,
-metadatas and the embeddings *as added* stay on the host, the role sqlite plays
-inside chromadb.  Search is exact, so results equal Chroma's only up to HNSW's
-approximation error.
+The vector segment (chromadb's HNSW index) is a FlatIndex on the GPU; ids and
+metadatas stay on the host, the role sqlite plays inside chromadb.  Embeddings
+are returned from the store itself (vdb_fetch: the L2-normalised fp32 row, which
+is also what chromadb's cosine-space segment hands back) — no second copy is
+kept in host memory.  Search is exact, so results equal Chroma's only up to
+HNSW's approximation error.
+
+Persistence is incremental (the reference adds 14 777 rows in three batches,
+src/vectordb.py:205-219, and chromadb itself persists per add): an add APPENDS
+its records to `records.jsonl` and its embeddings, as given, to `embeddings.f32`
+and then replaces the small `collection.json` whose `count` is the commit point
+(a torn append behind it is ignored on reopen).  The engine's own file
+`vectors.vdb` is only a cache for a fast reopen: it is written by persist() /
+close() when rows were added since, never per add, and a missing or stale one is
+rebuilt from `embeddings.f32`.
 """
 from __future__ import annotations
 
@@ -92,10 +103,10 @@ class Collection:
         self._id_to_row: Dict[str, int] = {}
         self._metadatas: List[Optional[dict]] = []
         self._documents: List[Optional[str]] = []
-        self._raw: List[np.ndarray] = []          # chunks of embeddings as added (fp32)
-        self._raw_cat: Optional[np.ndarray] = None
         self._index: Optional[FlatIndex] = None
         self._dim: Optional[int] = None
+        self._vdb_rows = -1                       # rows in the vectors.vdb on disk (-1: none / unknown)
+        self._rec_bytes: Optional[int] = 0        # committed length of records.jsonl (None: unknown)
 
     # -- internals ---------------------------------------------------------
     def _ensure_index(self, dim: int) -> FlatIndex:
@@ -106,13 +117,12 @@ class Collection:
             raise ValueError(f"Embedding dimension {dim} does not match collection dimensionality {self._dim}")
         return self._index
 
-    def _raw_matrix(self) -> np.ndarray:
-        if not self._raw:
+    def _stored_rows(self, rows) -> np.ndarray:
+        """The stored (L2-normalised, fp32) embeddings of the given row indices, from the engine."""
+        rows = np.asarray(rows, dtype=np.int64).reshape(-1)
+        if rows.size == 0 or self._index is None:
             return np.zeros((0, self._dim or 0), np.float32)
-        if self._raw_cat is None or len(self._raw) > 1:
-            self._raw_cat = np.concatenate(self._raw, axis=0)
-            self._raw = [self._raw_cat]
-        return self._raw_cat
+        return self._index.fetch(rows)
 
     def _kprime(self, k: int) -> int:
         if self._dtype != "bf16":
@@ -188,10 +198,8 @@ class Collection:
             self._ids.append(ids[j])
             self._metadatas.append(dict(metadatas[j]) if metadatas is not None and metadatas[j] is not None else None)
             self._documents.append(documents[j] if documents is not None else None)
-        self._raw.append(np.ascontiguousarray(emb))
-        self._raw_cat = None
         if self._auto_persist:
-            self.persist()
+            self._append_to_disk(base, np.ascontiguousarray(emb[: len(keep)], dtype=np.float32))
 
     def query(self, query_embeddings=None, query_texts=None, n_results: int = 10, where: Optional[dict] = None,
               where_document: Optional[dict] = None, include: Sequence[str] = _DEFAULT_QUERY_INCLUDE) -> Dict[str, Any]:
@@ -240,8 +248,9 @@ class Collection:
         if "documents" in include:
             out["documents"] = [[docs_[r] for r in rl] for rl in row_lists]
         if "embeddings" in include:
-            raw = self._raw_matrix()
-            out["embeddings"] = [self._format_embeddings(raw[rr]) for rr in rows]
+            flat = self._stored_rows(np.concatenate(rows) if rows else np.zeros(0, np.int64))   # one fetch for the batch
+            cuts = np.cumsum([0] + [len(rr) for rr in rows])
+            out["embeddings"] = [self._format_embeddings(flat[cuts[i]:cuts[i + 1]]) for i in range(b)]
         return out
 
     def _query_filtered(self, q: np.ndarray, n_results: int, where: dict):
@@ -263,7 +272,7 @@ class Collection:
             return rows, [dist[i][: len(rows[i])] for i in range(b)]
         sub = FlatIndex(self._dim, self._dtype, True, self._device, lib=self._lib)
         try:
-            sub.add(self._raw_matrix()[allowed])
+            sub.add(self._stored_rows(allowed))
             k = min(n_results, allowed.size)
             idx, dist = sub.search(q, k, self._kprime(k))
         finally:
@@ -292,9 +301,7 @@ class Collection:
         if "documents" in include:
             out["documents"] = [self._documents[r] for r in rows]
         if "embeddings" in include:
-            raw = self._raw_matrix()
-            out["embeddings"] = self._format_embeddings(raw[np.asarray(rows, dtype=np.int64)] if rows
-                                                        else np.zeros((0, self._dim or 0), np.float32))
+            out["embeddings"] = self._format_embeddings(self._stored_rows(rows))
         return out
 
     def peek(self, limit: int = 10) -> Dict[str, Any]:
@@ -304,19 +311,63 @@ class Collection:
     def _dir(self) -> str:
         return os.path.join(self._path, self.name)
 
+    def _write_manifest(self, d: str) -> None:
+        tmp = os.path.join(d, "collection.json.tmp")
+        with open(tmp, "w") as f:
+            json.dump({"name": self.name, "metadata": self.metadata, "dim": self._dim, "count": self.count()}, f)
+            f.flush()
+            os.fsync(f.fileno())
+        os.replace(tmp, os.path.join(d, "collection.json"))      # the commit point
+
+    def _append_to_disk(self, base: int, emb: np.ndarray) -> None:
+        """Persist one add: O(rows added), whatever the collection's size."""
+        d = self._dir()
+        os.makedirs(d, exist_ok=True)
+        rec_path, emb_path = os.path.join(d, "records.jsonl"), os.path.join(d, "embeddings.f32")
+        # a torn append of an earlier run may sit behind the committed count: cut it off before appending
+        if base == 0 or not os.path.exists(rec_path):
+            open(rec_path, "w").close()
+            open(emb_path, "wb").close()
+        elif self._rec_bytes is not None and os.path.getsize(rec_path) != self._rec_bytes:
+            os.truncate(rec_path, self._rec_bytes)
+        want = base * (self._dim or 0) * 4
+        if os.path.exists(emb_path) and os.path.getsize(emb_path) != want:
+            os.truncate(emb_path, want)
+        with open(rec_path, "a") as f:
+            for r in range(base, len(self._ids)):
+                f.write(json.dumps({"id": self._ids[r], "metadata": self._metadatas[r], "document": self._documents[r]}) + "\n")
+            f.flush()
+            os.fsync(f.fileno())
+            self._rec_bytes = f.tell()
+        with open(emb_path, "ab") as f:
+            emb.tofile(f)
+            f.flush()
+            os.fsync(f.fileno())
+        self._write_manifest(d)
+
     def persist(self) -> None:
+        """Bring the directory fully up to date: the manifest, and the engine's store file (a cache for a fast reopen)
+        when rows were added since it was written.  add() has already made the records and embeddings durable."""
         if self._path is None:
             return
         d = self._dir()
         os.makedirs(d, exist_ok=True)
-        with open(os.path.join(d, "collection.json"), "w") as f:
-            json.dump({"name": self.name, "metadata": self.metadata, "dim": self._dim, "count": self.count()}, f)
-        with open(os.path.join(d, "records.jsonl"), "w") as f:
-            for i, m, doc in zip(self._ids, self._metadatas, self._documents):
-                f.write(json.dumps({"id": i, "metadata": m, "document": doc}) + "\n")
-        if self._index is not None:
-            np.save(os.path.join(d, "embeddings.npy"), self._raw_matrix(), allow_pickle=False)
+        if not self._auto_persist and self.count():     # nothing was appended per add: write the whole collection once
+            self._rec_bytes = None
+            n = self.count()
+            tmp_r, tmp_e = os.path.join(d, "records.jsonl.tmp"), os.path.join(d, "embeddings.f32.tmp")
+            with open(tmp_r, "w") as f:
+                for i, m, doc in zip(self._ids, self._metadatas, self._documents):
+                    f.write(json.dumps({"id": i, "metadata": m, "document": doc}) + "\n")
+            with open(tmp_e, "wb") as f:
+                for lo in range(0, n, 65536):
+                    self._stored_rows(np.arange(lo, min(n, lo + 65536))).tofile(f)
+            os.replace(tmp_r, os.path.join(d, "records.jsonl"))
+            os.replace(tmp_e, os.path.join(d, "embeddings.f32"))
+        self._write_manifest(d)
+        if self._index is not None and self._vdb_rows != self.count():
             self._index.save(d)
+            self._vdb_rows = self.count()
 
     def _load(self) -> None:
         d = self._dir()
@@ -324,23 +375,62 @@ class Collection:
             info = json.load(f)
         self.metadata = info.get("metadata") or self.metadata
         self._dim = info.get("dim")
-        with open(os.path.join(d, "records.jsonl")) as f:
-            for line in f:
-                rec = json.loads(line)
-                self._id_to_row[rec["id"]] = len(self._ids)
-                self._ids.append(rec["id"])
-                self._metadatas.append(rec["metadata"])
-                self._documents.append(rec["document"])
-        if self._dim and os.path.exists(os.path.join(d, "vectors.vdb")):
-            self._raw = [np.load(os.path.join(d, "embeddings.npy"), allow_pickle=False)]
-            self._index = FlatIndex.load(d, self._dtype, True, self._device, lib=self._lib)
-            if self._index.count() != len(self._ids):
-                raise RuntimeError(f"corrupt collection {self.name}: {self._index.count()} vectors, {len(self._ids)} records")
+        count = int(info.get("count") or 0)
+        rec_path = os.path.join(d, "records.jsonl")
+        self._rec_bytes = 0
+        if count:
+            with open(rec_path, "rb") as f:
+                for _ in range(count):               # records behind the committed count are a torn append: ignored
+                    line = f.readline()
+                    if not line.endswith(b"\n"):
+                        raise RuntimeError(f"corrupt collection {self.name}: records.jsonl holds fewer than {count} records")
+                    rec = json.loads(line)
+                    self._id_to_row[rec["id"]] = len(self._ids)
+                    self._ids.append(rec["id"])
+                    self._metadatas.append(rec["metadata"])
+                    self._documents.append(rec["document"])
+                self._rec_bytes = f.tell()
+        if not (self._dim and count):
+            return
+        vdb = os.path.join(d, "vectors.vdb")
+        if os.path.exists(vdb):
+            with open(vdb, "rb") as f:
+                head = f.read(32)
+            if len(head) == 32 and int(np.frombuffer(head[16:24], dtype=np.int64)[0]) == count:
+                self._index = FlatIndex.load(d, self._dtype, True, self._device, lib=self._lib)
+                self._vdb_rows = count
+                return
+        # no (or a stale) store file: rebuild the index from the embeddings as they were added
+        emb_path, npy_path = os.path.join(d, "embeddings.f32"), os.path.join(d, "embeddings.npy")
+        if os.path.exists(emb_path) and os.path.getsize(emb_path) >= count * self._dim * 4:
+            raw = np.memmap(emb_path, dtype=np.float32, mode="r", shape=(count, self._dim))
+        elif os.path.exists(npy_path):                # directories written by round 1
+            raw = np.load(npy_path, allow_pickle=False)[:count]
+            raw.astype(np.float32).tofile(emb_path)
+        else:
+            raise RuntimeError(f"corrupt collection {self.name}: {count} records but no embeddings on disk")
+        index = self._ensure_index(self._dim)
+        index.reserve(count)
+        for lo in range(0, count, 65536):
+            index.add(np.ascontiguousarray(raw[lo:lo + 65536]))
+        if index.count() != count:
+            raise RuntimeError(f"corrupt collection {self.name}: {index.count()} vectors, {count} records")
 
     def _close(self) -> None:
         if self._index is not None:
+            if self._auto_persist and self._vdb_rows != self.count():
+                try:
+                    self.persist()
+                except Exception:          # a failed cache write must not mask the caller's own error path
+                    pass
             self._index.close()
             self._index = None
+
+    def __del__(self):  # pragma: no cover - best effort: refresh the reopen cache when the last reference goes
+        try:
+            self._close()
+        except Exception:
+            pass
 
 
 class PersistentClient:
@@ -399,8 +489,17 @@ class PersistentClient:
             raise ValueError(f"Collection {name} does not exist.")
         col = self._open.pop(name, None)
         if col is not None:
+            col._auto_persist = False         # about to be removed: no point refreshing its store file
             col._close()
         shutil.rmtree(os.path.join(self._path, name), ignore_errors=True)
+
+    def close(self) -> None:
+        """Write the store files of collections that grew since they were last written, and release the GPU memory.
+        Not part of Chroma's API (chromadb persists per add; so does this client — close() only refreshes the
+        fast-reopen cache)."""
+        for col in list(self._open.values()):
+            col._close()
+        self._open.clear()
 
 
 class EphemeralClient(PersistentClient):

@@ -1,0 +1,165 @@
+// k_mfma.hip — the batched bf16 path: Q.D^T on MFMA with the threshold/append protocol of scan_mfma3.h.
+// Host orchestration of one batched search (all buffers are the caller's) + the kernels' instantiations.
+#include <algorithm>
+#include <cmath>
+#include "launch.h"
+#include "scan_mfma4.h"
+#include "scan_mfma5.h"
+#include "scan_stream.h"
+
+namespace vdbk {
+namespace {
+
+struct MfGrid { int n_splits, xcd_map, tiles_per_split; };
+MfGrid mf_grid(int n_cu, int n_qt, long long pass_tiles, int max_splits) {
+  MfGrid g;
+  g.n_splits = (int)std::max<long long>(1, std::min<long long>(pass_tiles, std::max(1, std::min(max_splits, n_cu / n_qt))));
+  g.xcd_map = 0;
+  if (g.n_splits >= 8) { g.n_splits &= ~7; g.xcd_map = 1; }   // the n_qt blocks of a split share one XCD's L2
+  g.tiles_per_split = (int)((pass_tiles + g.n_splits - 1) / g.n_splits);
+  return g;
+}
+
+static_assert(kMfDenseLdC == kMf3DenseLd && kMfRowBytesC == kMfRowBytes, "launch.h mirrors the kernels' constants");
+
+#define MF_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return e_; } while (0)
+
+}  // namespace
+
+bool mfma_kk_supported(int kk) { return mfma_path_supported(kk); }
+
+// Which pass kernel serves a batch of b queries:
+//   b <= 64                         -> 6: the streaming kernel (scan_stream.h): corpus straight from HBM into MFMA
+//                                         fragments, no LDS staging of the corpus — HBM-bound like the GEMV scan;
+//   a 256-wide query tile pads the batch no more than 1.5x further than a 128-wide one -> 5 (scan_mfma5.h; it runs
+//                                         ~1.6x the rate of the 128-wide kernel: 13.4 vs 21.8 ms per 1024 queries x 10M rows);
+//   otherwise                       -> 4 (scan_mfma4.h).
+MfPlan mfma_plan(int b, int n_rows, int n_cu, int variant_opt) {
+  (void)n_rows;
+  MfPlan p;
+  p.n_qt_fb = (b + kMfBN - 1) / kMfBN;
+  const int pad_wide = ((b + kM5BN - 1) / kM5BN) * kM5BN;
+  const bool wide = variant_opt >= 5 && 2 * pad_wide <= 3 * p.n_qt_fb * kMfBN;
+  const bool stream = variant_opt >= 6 && b <= kStMaxB;
+  p.variant = stream ? 6 : wide ? 5 : 4;
+  p.n_qt = stream ? 1 : wide ? pad_wide / kM5BN : p.n_qt_fb;
+  p.b_pad = std::max(wide ? pad_wide : p.n_qt_fb * kMfBN, p.n_qt_fb * kMfBN);   // >= the fallback's 128-wide tiles either way
+  const long long n_tiles = ((long long)n_rows + kMfBM - 1) / kMfBM;
+  p.fb_splits = mf_grid(n_cu, p.n_qt_fb, n_tiles, 64).n_splits;                   // fallback grid (<= 64 partial lists per query)
+  return p;
+}
+
+hipError_t mfma_prepare_device() {
+  MF_TRY(hipFuncSetAttribute((const void*)scan_mfma_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_smem_bytes()));
+  MF_TRY(hipFuncSetAttribute((const void*)scan_mfma_ws_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_smem_bytes()));
+  MF_TRY(hipFuncSetAttribute((const void*)scan_mfma_ws_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_smem_bytes()));
+  MF_TRY(hipFuncSetAttribute((const void*)scan_mfma_wide_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m5_smem_bytes()));
+  MF_TRY(hipFuncSetAttribute((const void*)scan_mfma_wide_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m5_smem_bytes()));
+  MF_TRY(hipFuncSetAttribute((const void*)scan_mfma_wide_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m5_smem_bytes()));
+  MF_TRY(hipFuncSetAttribute((const void*)scan_mfma_wide_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m5_smem_bytes()));
+  MF_TRY(hipFuncSetAttribute((const void*)scan_mfma_wide_kernel<1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m5_smem_bytes()));
+  MF_TRY(stream_prepare_device());
+  return hipSuccess;
+}
+
+hipError_t mfma_search_launch(const MfSearchArgs& a, int* skipped_tiles) {
+  const int b = a.b, kk = a.kk, n_rows = a.n_rows, cap = a.cap, self0 = a.self0;
+  const MfPlan pl = mfma_plan(b, n_rows, a.n_cu, a.variant);
+  const int variant = pl.variant, n_qt = pl.n_qt, n_qt_fb = pl.n_qt_fb;
+  const long long n_tiles = ((long long)n_rows + kMfBM - 1) / kMfBM;
+  const unsigned char* rows = a.rows_bf16;
+  const unsigned char* qb16 = a.qb16;
+  float* cand_s = a.cand_s; int* cand_i = a.cand_i; int* cand_cnt = a.cand_cnt;
+  int* ovf = cand_cnt + b;
+  float* thr = a.thr; float* dense = a.dense;
+  hipStream_t st = a.st;
+  if (skipped_tiles) *skipped_tiles = 0;
+  const MfGrid fb = mf_grid(a.n_cu, n_qt_fb, n_tiles, 64);
+
+  hipLaunchKernelGGL(queries_to_bf16_kernel, dim3(std::min(1024, (pl.b_pad * kMfDim + 255) / 256)), dim3(256), 0, st,
+                     a.qn, b, pl.b_pad, (uint16_t*)a.qb16);
+  MF_TRY(hipGetLastError());
+  MF_TRY(hipMemsetAsync(ovf, 0, 4, st));
+
+  // one pass of whichever kernel serves this batch; mode 0 = dense sample, 1 = append
+  auto launch_pass = [&](int mode, long long pass_tiles, int stride, int skip_n) -> hipError_t {
+    if (variant == 6) {
+      stream_launch_pass(mode, rows, n_rows, qb16, b, (int)pass_tiles, stride, skip_n, self0, mode ? (const float*)thr : nullptr, dense,
+                         cand_cnt, cand_s, cand_i, cap, a.n_cu, a.stream_nt, st);
+      return hipGetLastError();
+    }
+    const MfGrid g = mf_grid(a.n_cu, n_qt, pass_tiles, 1 << 30);
+    if (variant == 5) {
+      if (mode == 0)
+        hipLaunchKernelGGL((scan_mfma_wide_kernel<0>), dim3(n_qt * g.n_splits), dim3(kM5Threads), m5_smem_bytes(), st, rows, n_rows, qb16, b,
+                           n_qt, g.n_splits, g.tiles_per_split, (int)pass_tiles, stride, self0, g.xcd_map, (const float*)nullptr, dense,
+                           (int*)nullptr, (float*)nullptr, (int*)nullptr, 0, 0, 0);
+      else {
+        auto kern = (a.ablate & 8) ? scan_mfma_wide_kernel<1, 3> : (a.ablate & 1) ? scan_mfma_wide_kernel<1, 1> : (a.ablate & 2) ? scan_mfma_wide_kernel<1, 2> : scan_mfma_wide_kernel<1, 0>;
+        hipLaunchKernelGGL(kern, dim3(n_qt * g.n_splits), dim3(kM5Threads), m5_smem_bytes(), st, rows, n_rows, qb16, b,
+                           n_qt, g.n_splits, g.tiles_per_split, (int)pass_tiles, stride, self0, g.xcd_map, (const float*)thr, dense,
+                           cand_cnt, cand_s, cand_i, cap, a.ablate, skip_n);
+      }
+    } else {
+      if (mode == 0)
+        hipLaunchKernelGGL((scan_mfma_ws_kernel<0>), dim3(n_qt * g.n_splits), dim3(kWsThreads), ws_smem_bytes(), st, rows, n_rows, qb16, b,
+                           n_qt, g.n_splits, g.tiles_per_split, (int)pass_tiles, stride, self0, g.xcd_map, (const float*)nullptr, dense,
+                           (int*)nullptr, (float*)nullptr, (int*)nullptr, 0, ovf, 0, 0);
+      else
+        hipLaunchKernelGGL((scan_mfma_ws_kernel<1>), dim3(n_qt * g.n_splits), dim3(kWsThreads), ws_smem_bytes(), st, rows, n_rows, qb16, b,
+                           n_qt, g.n_splits, g.tiles_per_split, (int)pass_tiles, stride, self0, g.xcd_map, (const float*)thr, dense,
+                           cand_cnt, cand_s, cand_i, cap, ovf, a.ablate, skip_n);
+    }
+    return hipGetLastError();
+  };
+
+  // pass 0: dense scores of a strided 16-tile sample -> t0 = a lower bound of the k'-th best per query
+  long long t_cur = std::min<long long>(n_tiles, kMf3DenseTiles);
+  {
+    const int stride = (int)std::max<long long>(1, n_tiles / t_cur);
+    MF_TRY(launch_pass(0, t_cur, stride, 0));
+    // rows of the dense matrix beyond the sampled tiles were never written: select over t_cur*256 columns only
+    // n_tiles == t_cur: the dense pass saw the whole store and the next pass is the last; either way a valid lower bound suffices
+    hipLaunchKernelGGL(dense_lower_bound_kernel, dim3(b), dim3(64), 0, st, dense, kMf3DenseLd, (int)t_cur * kMfBM, kk, thr);
+    MF_TRY(hipGetLastError());
+  }
+  // append passes over geometrically growing strided samples; the growth factor per pass is
+  // at most R = cap/(4 k') so that ~cap/4 candidates per query are expected in each
+  const double Rmax = std::max<double>(2.0, (double)cap / (4.0 * kk));
+  const double span = (double)n_tiles / (double)t_cur;
+  const int n_pass = span <= 1.0 ? 1 : std::max(1, (int)std::ceil(std::log(span) / std::log(Rmax) - 0.15));   // up to ~2x Rmax per pass
+  const double growth = std::pow(span, 1.0 / n_pass);
+  // Two passes (the usual case): the last one leaves out the tiles the sample pass multiplied and the final
+  // selection is seeded with the sample's sorted list instead — the sample is 2 % of the tiles at 10M rows,
+  // 6 % at an 8-GPU shard's 1.25M.
+  bool seeded = false;
+  int seed_stride = 0, seed_n = 0;   // the sample the seed list came from: tiles 0, stride, ..., (n-1)*stride
+  for (int pass = 1; pass <= n_pass; ++pass) {
+    const bool last = pass == n_pass;
+    long long t_next = last ? n_tiles : std::min<long long>(n_tiles, (long long)std::ceil((double)t_cur * growth));
+    if (!last && n_pass == 2) t_next = std::min<long long>(n_tiles, (long long)std::ceil((double)t_cur * std::pow(span, a.split_x1000 * 1e-3)));
+    int stride = last ? 1 : (int)std::max<long long>(1, n_tiles / t_next);
+    int skip_n = 0;
+    long long pass_tiles = t_next;
+    if (last && seeded) { stride = seed_stride; skip_n = seed_n; pass_tiles = n_tiles - skip_n; if (skipped_tiles) *skipped_tiles = skip_n; }
+    MF_TRY(hipMemsetAsync(cand_cnt, 0, (size_t)b * 4, st));
+    if (pass_tiles > 0) MF_TRY(launch_pass(1, pass_tiles, stride, skip_n));
+    // the sample pass of a two-pass search keeps its sorted list when the last pass can leave its tiles out
+    const bool keep = !last && n_pass == 2 && stride >= 2 && a.skip_sample;
+    hipLaunchKernelGGL(select_kth_kernel, dim3(b), dim3(1024), 0, st, (const float*)cand_s, (const int*)cand_i,
+                       (const int*)cand_cnt, cap, kk, thr, (last || keep) ? (last ? a.list_s : a.seed_s) : (float*)nullptr,
+                       (last || keep) ? (last ? a.list_i : a.seed_i) : (int*)nullptr, ovf,
+                       (last && seeded) ? (const float*)a.seed_s : (const float*)nullptr,
+                       (last && seeded) ? (const int*)a.seed_i : (const int*)nullptr);
+    MF_TRY(hipGetLastError());
+    if (keep) { seeded = true; seed_stride = stride; seed_n = (int)t_next; }
+    t_cur = t_next;
+  }
+  if (a.force_fallback) MF_TRY(hipMemsetAsync(ovf, 1, 1, st));
+  // exact list kernel: returns at once unless the overflow flag is set
+  hipLaunchKernelGGL(scan_mfma_topk_kernel, dim3(n_qt_fb * fb.n_splits), dim3(kMfThreads), mf_smem_bytes(), st, rows, n_rows, qb16, b,
+                     n_qt_fb, fb.n_splits, fb.tiles_per_split, kk, self0, fb.xcd_map, a.ablate, (const int*)ovf, a.part_s, a.part_i);
+  return hipGetLastError();
+}
+
+}  // namespace vdbk

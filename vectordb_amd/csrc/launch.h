@@ -1,0 +1,51 @@
+// launch.h — host-side seams between the translation units of libvdb_hip.so.
+// The kernels are heavy template families (72 GEMV-scan instantiations, the MFMA pass kernels);
+// each family compiles in its own TU (k_gemv.hip, k_mfma.hip, k_stream.hip) so that the library
+// builds in parallel and a change to one kernel rebuilds one file.  vdb_api.hip (the C ABI and all
+// orchestration) sees only these plain functions.  No device symbol crosses a TU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace vdbk {
+
+// ---- k_gemv.hip: the HBM-bound scan (scan_gemv.h) ---------------------------------------------
+struct ScanArgs {
+  const void* rows; int n_rows; const float* qn; int kk; int self0; const unsigned* allow; float* part_s; int* part_i;
+  int grid; hipStream_t st; size_t smem;
+};
+// compile-time row length (768 or 384), qb in {1,2,4} queries per corpus pass, e = list entries per lane
+bool launch_scan_fast(bool bf16, int dim, const ScanArgs& a, int qb, int e, bool nt);
+// any padded row length ld, one query per pass
+bool launch_scan_any(bool bf16, const ScanArgs& a, int ld, int e, bool nt);
+
+// ---- k_mfma.hip: the batched bf16 path (scan_mfma{,3,4,5}.h) ----------------------------------
+// One batched search over device-resident, normalised fp32 queries: dense sample -> thresholds -> append
+// passes -> exact top-k' lists (list_*), with the exact list kernel as the device-flagged overflow fallback
+// (part_*).  Every buffer is the caller's; nothing is allocated here.
+struct MfSearchArgs {
+  const unsigned char* rows_bf16; int n_rows; const float* qn; int b; int kk; int self0;
+  int n_cu; int variant;           // 4 = 256x128 warp-specialised, 5 = 256x256 wide tile, 6 = streaming (<= 64 queries)
+  int cap; int split_x1000; int skip_sample; int force_fallback; int ablate; int stream_nt;
+  unsigned char* qb16;             // [b_pad][768] bf16
+  float* cand_s; int* cand_i;      // [b][cap]
+  int* cand_cnt;                   // [b] + overflow flag at [b]
+  float* thr;                      // [b]
+  float* dense;                    // [b][kMf3DenseLd]
+  float* list_s; int* list_i;      // [b][kk]   result lists
+  float* seed_s; int* seed_i;      // [b][kk]
+  float* part_s; int* part_i;      // [b][fb_splits][kk]   fallback partial lists
+  hipStream_t st;
+};
+struct MfPlan { int variant; int n_qt; int b_pad; int n_qt_fb; int fb_splits; };
+constexpr int kMfDenseLdC = 4096;       // floats per query of the dense sample (16 tiles x 256 rows; k_mfma.hip asserts it)
+constexpr int kMfRowBytesC = 1536;      // the batched path serves 768-d bf16 rows
+constexpr int kMfMaxQueriesPerCall = 4096;   // mfma_search_launch serves at most this many queries (the caller chunks)
+MfPlan mfma_plan(int b, int n_rows, int n_cu, int variant_opt);
+hipError_t mfma_prepare_device();                    // raise the dynamic-LDS limits of the kernels on the current device
+// returns hipSuccess or the launch error; *skipped_tiles = tiles the final pass left out
+hipError_t mfma_search_launch(const MfSearchArgs& a, int* skipped_tiles);
+bool mfma_kk_supported(int kk);
+
+}  // namespace vdbk

@@ -2,36 +2,42 @@
 // (report against the vendor peaks AND against measured ones): a streaming
 // HBM read of the index's own rows and a bare bf16 MFMA loop.  Read through vdb_get_stat.
 #pragma once
-#include "scan_mfma.h"
+#include <hip/hip_runtime.h>
 
 namespace vdbk {
 
 typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+typedef __bf16 pr_bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float pr_f32x16_t __attribute__((ext_vector_type(16)));
 
-// every lane streams 16-byte chunks, U in flight, non-temporal (the scan kernel's access shape)
+// The scan kernel's own access shape (scan_gemv.h) with the arithmetic taken out: a wave owns one contiguous
+// U KiB tile at a time (U 16-byte loads per lane, 1 KiB per wave-instruction, non-temporal), tiles are dealt
+// round-robin to the waves of the grid.  Launched like the scan (256 threads, 2 or 4 blocks per CU), so that
+// what it measures is a ceiling FOR the scan, not another kernel's rate.
 template <int U>
 __global__ __launch_bounds__(256) void probe_read_kernel(const v4u_t* __restrict__ p, size_t n16, unsigned* __restrict__ sink) {
-  const size_t stride = (size_t)gridDim.x * 256;
-  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t lane = threadIdx.x & 63;
+  const size_t gw = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (size_t)gridDim.x * 4;
+  const size_t n_tiles = n16 / (U * 64);
   unsigned acc = 0;
-  for (; i + (U - 1) * stride < n16; i += U * stride) {
+  for (size_t t = gw; t < n_tiles; t += nw) {
+    const v4u_t* q = p + t * (U * 64) + lane;
     v4u_t v[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(p + i + u * stride);
+    for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(q + u * 64);
 #pragma unroll
     for (int u = 0; u < U; ++u) acc ^= v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
   }
-  for (; i < n16; i += stride) { const v4u_t a = __builtin_nontemporal_load(p + i); acc ^= a.x ^ a.y ^ a.z ^ a.w; }
   if (acc == 0x9E3779B9u) *sink = acc;   // keeps the loads alive; practically never true
 }
 
 // operands in registers, 8 independent accumulators per wave, two waves per SIMD
 __global__ __launch_bounds__(512) void probe_mfma_kernel(int iters, float* __restrict__ sink) {
   const int lane = threadIdx.x & 63;
-  bf16x8_t a, b;
+  pr_bf16x8_t a, b;
 #pragma unroll
   for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(0.001f * (float)((lane + i) & 15)); b[i] = (__bf16)(0.002f * (float)((lane * 3 + i) & 7)); }
-  f32x16_t acc[8];
+  pr_f32x16_t acc[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j)
 #pragma unroll

@@ -16,12 +16,11 @@
 // ordering), a device-side flag routes the batch through the exact list kernel instead.
 // Extra work: the samples add ~1-2 % to the contraction.
 //
-// Main loop (one 512-thread block per CU, tile 256 corpus rows x 128 queries, K in 12
-// steps of 64): 3-stage LDS ring filled by global_load_lds_dwordx4 with scalar base +
-// per-thread constant 32-bit offsets (no per-step VALU address math), counted
-// s_waitcnt vmcnt(6) + raw s_barrier so two stages stay in flight, all 16 fragment
-// ds_read_b128 of a step issued before its 16 MFMAs, waves 4-7 issue their loads after
-// their MFMAs (de-phases the two waves of a SIMD).
+// This header holds the protocol's selection kernels; the pass kernels themselves are
+// scan_mfma4.h (256 x 128 tile, warp-specialised), scan_mfma5.h (256 x 256 tile) and
+// scan_stream.h (<= 64 queries, corpus straight from HBM into MFMA fragments).  The first
+// pass kernel of this protocol (a barrier ring on a 256 x 128 tile) was retired in round 2:
+// no shape was left where it won.
 #pragma once
 #include "scan_mfma.h"
 
@@ -29,166 +28,6 @@ namespace vdbk {
 
 constexpr int kMf3DenseTiles = 16;                     // dense sample: 16 tiles = 4096 rows
 constexpr int kMf3DenseLd = kMf3DenseTiles * kMfBM;
-
-// MODE 0: dense sample scores -> dense[q][t*256 + r].  MODE 1: append hits to cand_*[q][cap].
-template <int MODE>
-__global__ __launch_bounds__(kMfThreads) void scan_mfma_pass_kernel(
-    const unsigned char* __restrict__ rows, int n_rows, const unsigned char* __restrict__ qb16, int b, int n_qtiles,
-    int n_splits, int tiles_per_split, int n_pass_tiles, int tile_stride, int self0, int xcd_map,
-    const float* __restrict__ thr_in, float* __restrict__ dense, int* __restrict__ cand_cnt,
-    float* __restrict__ cand_s, int* __restrict__ cand_i, int cap) {
-  extern __shared__ __align__(16) unsigned char smem[];   // the only LDS object: 3 stages
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: keeps the wave-role branches and the staging cursor in SGPRs
-  const int wm = w >> 1, wn = w & 1;
-  const int hsel = lane >> 5;
-
-  int qt, sp;
-  if (xcd_map) {
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    qt = j % n_qtiles;
-    sp = xcd * (n_splits >> 3) + j / n_qtiles;
-  } else {
-    qt = blockIdx.x % n_qtiles;
-    sp = blockIdx.x / n_qtiles;
-  }
-  const int qbase = qt * kMfBN;
-  const int tile0 = sp * tiles_per_split;                               // pass-local tile index
-  const int tile1 = min(tile0 + tiles_per_split, n_pass_tiles);
-  const int my_tiles = tile1 > tile0 ? tile1 - tile0 : 0;
-  const int total_steps = my_tiles * kMfSteps;
-  if (total_steps == 0) return;
-
-  // thresholds of this lane's two query columns (fixed for the whole pass)
-  float thr[2] = {-INFINITY, -INFINITY};
-  if (MODE == 1 && thr_in) {
-    const int q0 = qbase + wn * 64 + (lane & 31);
-    thr[0] = thr_in[min(q0, b - 1)];
-    thr[1] = thr_in[min(q0 + 32, b - 1)];
-  }
-  // retire the threshold loads here: a first use inside the loop would make hipcc wait vmcnt(0)
-  // (draining the two staged tiles in flight) at every tile's epilogue
-  asm volatile("" :: "v"(thr[0]), "v"(thr[1]));
-
-  // per-thread constant offsets: staging sources (bytes inside a tile) and fragment reads
-  unsigned a_off[4], b_off[2];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int L = t * kMfThreads + tid, r = L >> 3, c = (L & 7) ^ ((r >> 1) & 7);
-    a_off[t] = (unsigned)(r * kMfRowBytes + c * 16);
-  }
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int L = t * kMfThreads + tid, r = L >> 3, c = (L & 7) ^ ((r >> 1) & 7);
-    b_off[t] = (unsigned)(r * kMfRowBytes + c * 16);
-  }
-  const int ar0 = wm * 64 + (lane & 31), ar1 = ar0 + 32;
-  const int br0 = wn * 64 + (lane & 31), br1 = br0 + 32;
-  int fa0[4], fa1[4], fb0[4], fb1[4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    const int c = 2 * s + hsel;
-    fa0[s] = ar0 * 128 + ((c ^ ((ar0 >> 1) & 7)) << 4);
-    fa1[s] = ar1 * 128 + ((c ^ ((ar1 >> 1) & 7)) << 4);
-    fb0[s] = kMfStageA + br0 * 128 + ((c ^ ((br0 >> 1) & 7)) << 4);
-    fb1[s] = kMfStageA + br1 * 128 + ((c ^ ((br1 >> 1) & 7)) << 4);
-  }
-  const int wbase16 = w * 1024;                       // this wave's 1 KiB slot inside a piece
-  const unsigned char* qblk = qb16 + (size_t)qbase * kMfRowBytes;
-
-  // staging cursor (scalar): next (tile, k-step) to issue
-  int is_tile = 0, is_ks = 0;
-  auto issue = [&](int buf) {
-    const unsigned char* abase = rows + (size_t)(tile0 + is_tile) * tile_stride * (kMfBM * kMfRowBytes) + is_ks * (kMfBK * 2);
-    const unsigned char* bbase = qblk + is_ks * (kMfBK * 2);
-    unsigned char* st = smem + buf * kMfStage + wbase16;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) mf_glds16(abase + a_off[t], st + t * (kMfThreads * 16));
-#pragma unroll
-    for (int t = 0; t < 2; ++t) mf_glds16(bbase + b_off[t], st + kMfStageA + t * (kMfThreads * 16));
-    if (++is_ks == kMfSteps) { is_ks = 0; ++is_tile; }
-  };
-
-  f32x16_t acc[2][2];
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
-
-  issue(0);
-  if (total_steps > 1) issue(1);
-  const bool late = w >= 4;
-
-  int buf = 0, ks = 0, tile = 0;
-  for (int step = 0; step < total_steps; ++step) {
-    if (step + 1 < total_steps) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    const bool do_issue = step + 2 < total_steps;
-    const int nbuf = buf == 0 ? 2 : buf - 1;                  // (step+2) % 3
-    if (do_issue && !late) issue(nbuf);
-
-    const unsigned char* sb = smem + buf * kMfStage;
-    bf16x8_t a0[4], a1[4], b0[4], b1[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      a0[s] = *reinterpret_cast<const bf16x8_t*>(sb + fa0[s]);
-      b0[s] = *reinterpret_cast<const bf16x8_t*>(sb + fb0[s]);
-      a1[s] = *reinterpret_cast<const bf16x8_t*>(sb + fa1[s]);
-      b1[s] = *reinterpret_cast<const bf16x8_t*>(sb + fb1[s]);
-    }
-    // pin the schedule: all 16 fragment reads are in flight before the first MFMA (hipcc otherwise
-    // re-serialises them into 4 x [4 reads, wait, 4 MFMAs] on one register set, exposing LDS latency)
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[s], b0[s], acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[s], b1[s], acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[s], b0[s], acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[s], b1[s], acc[1][1], 0, 0, 0);
-    }
-    if (do_issue && late) issue(nbuf);
-    buf = buf == 2 ? 0 : buf + 1;
-    if (++ks < kMfSteps) continue;
-    ks = 0;
-
-    // ---------------- epilogue of pass-local tile (tile0 + tile) ----------------
-    const long long tile_row0 = (long long)(tile0 + tile) * tile_stride * kMfBM;
-    const bool needs_mask = (tile_row0 + kMfBM > n_rows) || (qbase + kMfBN > b) || (self0 >= 0);
-#pragma unroll
-    for (int idx = 0; idx < 64; ++idx) {
-      const int mt = idx >> 5, nt = (idx >> 4) & 1, reg = idx & 15;
-      const float v = acc[mt][nt][reg];
-      const int rloc = wm * 64 + mt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hsel;
-      const int qg = qbase + wn * 64 + nt * 32 + (lane & 31);
-      if (MODE == 0) {
-        const int row = (int)tile_row0 + rloc;
-        const bool ok = (row < n_rows) && !(self0 >= 0 && row == self0 + qg);
-        if (qg < b) dense[(size_t)qg * kMf3DenseLd + (tile0 + tile) * kMfBM + rloc] = ok ? v : -INFINITY;
-      } else {
-        bool pass = v >= thr[nt];
-        if (__ballot(pass) == 0ull) continue;          // the common case
-        const int row = (int)tile_row0 + rloc;
-        if (needs_mask) pass = pass && (row < n_rows) && (qg < b) && !(self0 >= 0 && row == self0 + qg);
-        if (pass) {
-          const int pos = atomicAdd(&cand_cnt[qg], 1);
-          if (pos < cap) { cand_s[(size_t)qg * cap + pos] = v; cand_i[(size_t)qg * cap + pos] = row; }
-        }
-      }
-    }
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
-    ++tile;
-  }
-}
 
 // Per query: the k'-th best of its candidates -> thr_out[q]; optionally the sorted top-k'
 // list -> list_*[q][kk].  Candidates: dense scores (cand_i == nullptr, index = position) or

@@ -1,23 +1,24 @@
 // vdb_api.hip — C ABI (include/vdb.h) of the MI355X-native cosine top-k engine.
-// Host-side orchestration only: all arithmetic is in the HIP kernels of scan_gemv.h (batch-1 / small
-// batches, HBM-bound), scan_mfma{,3,4,5}.h (batched bf16 path on MFMA) and select.h (merges, fp32 rerank,
-// shard merge).  gfx950 only; no CPU fallback.
+// Host-side orchestration only: all arithmetic is in the HIP kernels of scan_gemv.h (batch-1, HBM-bound;
+// instantiated in k_gemv.hip), scan_stream.h / scan_mfma{,3,4,5}.h (batched bf16 path on MFMA; k_mfma.hip) and
+// select.h (merges, fp32 rerank, shard merge; here).  gfx950 only; no CPU fallback.
 #include <hip/hip_runtime.h>
+#include <errno.h>
 #include <sys/stat.h>
+#include <unistd.h>
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
 #include "../../include/vdb.h"
-#include "scan_gemv.h"
+#include "launch.h"
 #include "select.h"
 #include "synth.h"
-#include "scan_mfma4.h"
-#include "scan_mfma5.h"
 #include "probes.h"
 
 using namespace vdbk;
@@ -39,6 +40,7 @@ struct vdb {
   float* rows_f32 = nullptr;      // [cap][ld] normalised fp32 (dtype f32, or rerank copy)
   uint16_t* rows_bf16 = nullptr;  // [cap][ld] bf16 (dtype bf16)
   hipStream_t stream = nullptr;
+  hipStream_t copy_stream = nullptr;   // D2H of self-join blocks while the next block computes (created on first use)
   std::vector<hipEvent_t> ring;   // timing ring: 3 events (start, scan end, finish) per recorded search
   hipEvent_t* ev = nullptr;       // triple of the search in flight
   int64_t n_timed = 0;            // searches recorded since the ring was (re)set
@@ -47,30 +49,42 @@ struct vdb {
   int64_t n_calls = 0;
   bool ev_on = true;              // this search is a timed one
   double last_bytes = 0.0;
+  int last_path = 0;              // kernel family of the last search: 0 = GEMV scan, 4/5/6 = MFMA pass kernels (launch.h)
+  int last_passes = 0;            // corpus passes of the last search (GEMV: launches; MFMA: 1)
   int n_cu = 256;
   // options
   int scan_blocks_per_cu = 2;    // 2 x 256 threads per CU: 96 KiB in flight per CU; 4 measured 3-4 % slower at every shard size (bf16)
   int scan_nt_loads = 1;
-  int batch_mfma_min_b = 3;      // smallest batch the MFMA path may serve (the cost model decides above it)
+  int batch_mfma_min_b = 2;      // smallest batch the MFMA path may serve (the cost model decides above it)
   bool mfma_attr_set = false;    // dynamic-LDS limits of the MFMA kernels raised on this handle's device
   int mfma_cost_model = 1;       // 0: every supported batch >= batch_mfma_min_b takes the MFMA path (tests)
   int mfma_ablate = 0;   // diagnostic: skip parts of the MFMA kernel (wrong results, timing only)
+  int stream_nt = 0;     // the streaming kernel's corpus loads: 0 = plain, 1 = non-temporal
   // workspaces (grown on demand)
   DevBuf w_q, w_part_s, w_part_i, w_part2_s, w_part2_i, w_stage, w_out_i, w_out_d, w_idx, w_mfma;
   DevBuf w_q1, w_part_s1, w_part_i1, w_part2_s1, w_part2_i1;   // second set: slot 1 of the two-phase search
   struct Split { bool pending = false; int b = 0, k = 0, kp = 0, grid = 0; hipEvent_t* ev = nullptr; bool ev_on = false; } split[2];
   DevBuf w_cand_s, w_cand_i, w_cand_cnt, w_thr, w_dense, w_list_s, w_list_i;   // append-path state
   DevBuf w_seed_s, w_seed_i;      // the sample pass's sorted list (seeds the final selection)
+  DevBuf w_fb_s, w_fb_i;          // partial lists of the MFMA path's overflow fallback (never shared with a pending split scan)
   int mfma_skip_sample = 1;       // 1: the last of two passes leaves out the sample pass's tiles
   void* pin = nullptr; size_t pin_bytes = 0;                                     // pinned host staging for small host-pointer searches
   DevBuf w_mask;                                                                // host-supplied eligibility bitmap (vdb_search_masked)
   int mfma_append_cap = 16384;   // candidate buffer entries per query
   int mfma_split_x1000 = 500;    // two append passes: the sample pass covers span^(x/1000) times the dense sample (500 = geometric mean)
-  int mfma_variant = 5;          // 3 = barrier ring (scan_mfma3.h), 4 = warp-specialised (scan_mfma4.h),
-                                 // 5 = 256x256 tile (scan_mfma5.h) unless it pads the batch > 1.5x further, then 4
+  int mfma_variant = 6;          // 4 = warp-specialised 256x128 tile (scan_mfma4.h); 5 = + the 256x256 tile (scan_mfma5.h)
+                                 // where it pads the batch <= 1.5x further; 6 = + the streaming kernel (scan_stream.h) for <= 64 queries
   int mfma_last_b = 0;           // batch size of the last MFMA search (locates its overflow flag)
   int mfma_last_skipped = 0;     // tiles the last MFMA search's final pass left out (the sample pass's)
   int mfma_force_fallback = 0;   // test hook: route through the exact list kernel
+  // ---- sharded handle (vdb_create_sharded): a router over per-device shards; none of the fields above but
+  // dim/ld/dtype/keep_f32/device(= shard 0's)/stream/pin/w_stage/w_out_i/w_gather are used on it
+  std::vector<vdb*> shards;
+  std::vector<hipEvent_t> shard_done;   // per shard: its result is in the gather buffer
+  std::vector<char> shard_direct;       // per shard: its finish kernel stores straight into shard 0's memory (same device or P2P)
+  hipEvent_t ev_q = nullptr;            // the queries are ready on the caller's stream
+  int64_t per = 0;                      // rows per shard (multiple of 256); 0 = not reserved yet
+  DevBuf w_gather;                      // on shard 0's device: [g][b][k] idx (int64) then [g][b][k] dist (fp32)
   std::string err;
 };
 
@@ -88,6 +102,10 @@ int fail(vdb_t* h, int code, const std::string& msg) {
       return fail((h), e_ == hipErrorOutOfMemory ? VDB_ERR_MEMORY : VDB_ERR_DEVICE,               \
                   std::string(#expr) + ": " + hipGetErrorString(e_));                             \
   } while (0)
+
+bool is_sharded(const vdb_t* h) { return !h->shards.empty(); }
+#define NOT_ON_SHARDED(h, what) \
+  do { if (is_sharded(h)) return fail((h), VDB_ERR_STATE, what ": not available on a sharded handle"); } while (0)
 
 int ensure(vdb_t* h, DevBuf& b, size_t bytes) {
   if (bytes <= b.bytes) return VDB_OK;
@@ -108,7 +126,7 @@ int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 int grow(vdb_t* h, int64_t want_rows) {
   if (want_rows <= h->cap) return VDB_OK;
-  want_rows = (want_rows + 255) / 256 * 256;   // the MFMA kernel reads whole 256-row tiles (tail rows are masked)
+  want_rows = (want_rows + 255) / 256 * 256;   // the MFMA kernels read whole 256-row tiles (tail rows are masked)
   const size_t ld = (size_t)h->ld;
   if (h->keep_f32) {
     float* p = nullptr;
@@ -121,6 +139,8 @@ int grow(vdb_t* h, int64_t want_rows) {
   if (h->dtype == VDB_BF16) {
     uint16_t* p = nullptr;
     HIP_TRY(h, hipMalloc((void**)&p, sizeof(uint16_t) * ld * (size_t)want_rows));
+    // rows beyond n are read (and masked) by the tiled kernels: keep them finite
+    HIP_TRY(h, hipMemsetAsync(p, 0, sizeof(uint16_t) * ld * (size_t)want_rows, h->stream));
     if (h->n) HIP_TRY(h, hipMemcpyAsync(p, h->rows_bf16, sizeof(uint16_t) * ld * (size_t)h->n, hipMemcpyDeviceToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (h->rows_bf16) HIP_TRY(h, hipFree(h->rows_bf16));
@@ -149,56 +169,6 @@ int normalize_into_store(vdb_t* h, const float* raw_dev, int in_ld, int64_t n, h
   return VDB_OK;
 }
 
-// ---- scan dispatch ---------------------------------------------------------
-struct ScanArgs {
-  const void* rows; int n_rows; const float* qn; int kk; int self0; const unsigned* allow; float* part_s; int* part_i;
-  int grid; hipStream_t st; size_t smem;
-};
-
-template <typename T, int DIM, int QB, int E>
-void launch_scan_t(const ScanArgs& a, bool nt) {
-  if (nt)
-    hipLaunchKernelGGL((scan_topk_kernel<T, DIM, QB, E, true>), dim3(a.grid), dim3(kScanThreads), a.smem, a.st, a.rows, a.n_rows, a.qn, a.kk, a.self0, a.allow, a.part_s, a.part_i);
-  else
-    hipLaunchKernelGGL((scan_topk_kernel<T, DIM, QB, E, false>), dim3(a.grid), dim3(kScanThreads), a.smem, a.st, a.rows, a.n_rows, a.qn, a.kk, a.self0, a.allow, a.part_s, a.part_i);
-}
-
-template <typename T, int DIM>
-bool launch_scan_dim(const ScanArgs& a, int qb, int e, bool nt) {
-  if (qb == 1) {
-    switch (e) {
-      case 1: launch_scan_t<T, DIM, 1, 1>(a, nt); return true;
-      case 2: launch_scan_t<T, DIM, 1, 2>(a, nt); return true;
-      case 4: launch_scan_t<T, DIM, 1, 4>(a, nt); return true;
-      case 8: launch_scan_t<T, DIM, 1, 8>(a, nt); return true;
-      case 16: launch_scan_t<T, DIM, 1, 16>(a, nt); return true;
-    }
-  } else if (qb == 2) {
-    switch (e) {
-      case 1: launch_scan_t<T, DIM, 2, 1>(a, nt); return true;
-      case 2: launch_scan_t<T, DIM, 2, 2>(a, nt); return true;
-    }
-  } else if (qb == 4) {
-    switch (e) {
-      case 1: launch_scan_t<T, DIM, 4, 1>(a, nt); return true;
-      case 2: launch_scan_t<T, DIM, 4, 2>(a, nt); return true;
-    }
-  }
-  return false;
-}
-
-template <typename T>
-bool launch_scan_generic(const ScanArgs& a, int ld, int e, bool nt) {
-#define GEN_CASE(EE)                                                                                              \
-  case EE:                                                                                                        \
-    if (nt) hipLaunchKernelGGL((scan_topk_generic_kernel<T, EE, true>), dim3(a.grid), dim3(kScanThreads), a.smem, a.st, a.rows, a.n_rows, ld, a.qn, a.kk, a.self0, a.allow, a.part_s, a.part_i); \
-    else hipLaunchKernelGGL((scan_topk_generic_kernel<T, EE, false>), dim3(a.grid), dim3(kScanThreads), a.smem, a.st, a.rows, a.n_rows, ld, a.qn, a.kk, a.self0, a.allow, a.part_s, a.part_i);   \
-    return true;
-  switch (e) { GEN_CASE(1) GEN_CASE(2) GEN_CASE(4) GEN_CASE(8) GEN_CASE(16) }
-#undef GEN_CASE
-  return false;
-}
-
 int entries_for(int kk) {
   int e = (kk + 63) / 64;
   int p = 1;
@@ -221,22 +191,25 @@ void launch_merge(int e, const float* is, const int* ii, int n_cand, int cpb, in
   }
 }
 
-// The GEMV path's workspaces exist twice: slot 1 lets phase 2 of one batch (merge, rerank) run on another
-// stream while phase 1 of the next batch (normalise, scan) fills slot 0, and vice versa.
+// Where a GEMV-path search keeps its partial lists: two generations [q][part][kk] of (score, row).  The handle owns
+// two such sets (slot 1 lets phase 2 of one batch run on another stream while phase 1 of the next fills slot 0);
+// callers may bring their own.
+struct WsPtrs { float* ps; int* pi; float* p2s; int* p2i; };
 struct WsSet { DevBuf *q, *ps, *pi, *p2s, *p2i; };
 WsSet ws_of(vdb_t* h, int slot) {
   return slot ? WsSet{&h->w_q1, &h->w_part_s1, &h->w_part_i1, &h->w_part2_s1, &h->w_part2_i1}
               : WsSet{&h->w_q, &h->w_part_s, &h->w_part_i, &h->w_part2_s, &h->w_part2_i};
 }
+WsPtrs ptrs_of(const WsSet& W) { return WsPtrs{(float*)W.ps->p, (int*)W.pi->p, (float*)W.p2s->p, (int*)W.p2i->p}; }
 
 // Reduce the [b][n_parts][kk] partial lists of one query chunk to the b x k outputs:
 // hierarchical merge, then fp32 rerank (kp != 0) or plain ranking.
-int finish_search(vdb_t* h, const WsSet& W, int b, int n_parts, int kk, int k, int kp, const float* qn, int64_t* oi, float* od,
+int finish_search(vdb_t* h, const WsPtrs& W, int b, int n_parts, int kk, int k, int kp, const float* qn, int64_t* oi, float* od,
                   hipStream_t st) {
-  float* cur_s = (float*)W.ps->p;
-  int* cur_i = (int*)W.pi->p;
-  float* oth_s = (float*)W.p2s->p;
-  int* oth_i = (int*)W.p2i->p;
+  float* cur_s = W.ps;
+  int* cur_i = W.pi;
+  float* oth_s = W.p2s;
+  int* oth_i = W.p2i;
   const int e = entries_for(kk);
   int lists = n_parts;
   if (e == 1) {
@@ -278,190 +251,78 @@ int finish_search(vdb_t* h, const WsSet& W, int b, int n_parts, int kk, int k, i
   return VDB_OK;
 }
 
-// Batched bf16 path (scan_mfma3.h): dense sample -> thresholds -> append passes over
-// growing strided samples -> full pass -> exact top-k' lists; exact list kernel
-// (scan_mfma.h) as the device-flagged overflow fallback; then the shared fp32 finish.
-struct MfGrid { int n_splits, xcd_map, tiles_per_split; };
-MfGrid mf_grid(int n_cu, int n_qt, long long pass_tiles, int max_splits) {
-  MfGrid g;
-  g.n_splits = (int)std::max<long long>(1, std::min<long long>(pass_tiles, std::max(1, std::min(max_splits, n_cu / n_qt))));
-  g.xcd_map = 0;
-  if (g.n_splits >= 8) { g.n_splits &= ~7; g.xcd_map = 1; }   // the n_qt blocks of a split share one XCD's L2
-  g.tiles_per_split = (int)((pass_tiles + g.n_splits - 1) / g.n_splits);
-  return g;
-}
-
+// Batched bf16 path (k_mfma.hip): dense sample -> thresholds -> append passes over growing strided samples ->
+// full pass -> exact top-k' lists; exact list kernel as the device-flagged overflow fallback; then the shared
+// fp32 finish.  At most kMfMaxQueriesPerCall queries per call: the candidate buffers are b x cap x 8 bytes.
 int mfma_search(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_row0, int64_t* out_idx,
-                float* out_dist, hipStream_t st) {
+                float* out_dist, hipStream_t st, bool last_chunk) {
   const int kk = kp ? kp : k;
   const int n_rows = (int)h->n;
-  const int n_qt_fb = (b + kMfBN - 1) / kMfBN;          // query tiles of the 128-wide kernels (incl. the fallback)
-  // the 256-wide tile runs ~1.6x the rate of the 128-wide kernels (13.4 vs 21.8 ms per 1024 queries x 10M
-  // rows), so it serves the batch unless it pads it more than that much further than the 128-wide tile does
-  const int pad_wide = ((b + kM5BN - 1) / kM5BN) * kM5BN;
-  const bool wide = h->mfma_variant == 5 && 2 * pad_wide <= 3 * n_qt_fb * kMfBN;
-  const int variant = h->mfma_variant == 5 ? (wide ? 5 : 4) : h->mfma_variant;
-  const int n_qt = wide ? pad_wide / kM5BN : n_qt_fb;
-  const int b_pad = wide ? pad_wide : n_qt_fb * kMfBN;   // >= n_qt_fb * 128 either way (the fallback's tiles)
-  const long long n_tiles = ((long long)n_rows + kMfBM - 1) / kMfBM;
+  const MfPlan pl = mfma_plan(b, n_rows, h->n_cu, h->mfma_variant);
   const int cap = h->mfma_append_cap;
-  const int self0 = self_row0 >= 0 ? (int)self_row0 : -1;
-  const unsigned char* rows = (const unsigned char*)h->rows_bf16;
   int rc;
-  if ((rc = ensure(h, h->w_mfma, (size_t)b_pad * kMfDim * 2))) return rc;
+  if ((rc = ensure(h, h->w_mfma, (size_t)pl.b_pad * kMfRowBytesC))) return rc;
   if ((rc = ensure(h, h->w_cand_s, (size_t)b * cap * 4))) return rc;
   if ((rc = ensure(h, h->w_cand_i, (size_t)b * cap * 4))) return rc;
   if ((rc = ensure(h, h->w_cand_cnt, (size_t)(b + 16) * 4))) return rc;   // [b] counters + overflow flag at [b]
   if ((rc = ensure(h, h->w_thr, (size_t)b * 4))) return rc;
-  if ((rc = ensure(h, h->w_dense, (size_t)b * kMf3DenseLd * 4))) return rc;
+  if ((rc = ensure(h, h->w_dense, (size_t)b * kMfDenseLdC * 4))) return rc;
   if ((rc = ensure(h, h->w_list_s, (size_t)b * kk * 4))) return rc;
   if ((rc = ensure(h, h->w_list_i, (size_t)b * kk * 4))) return rc;
   if ((rc = ensure(h, h->w_seed_s, (size_t)b * kk * 4))) return rc;
   if ((rc = ensure(h, h->w_seed_i, (size_t)b * kk * 4))) return rc;
-  const MfGrid fb = mf_grid(h->n_cu, n_qt_fb, n_tiles, 64);   // fallback grid (<= 64 partial lists per query)
-  const size_t part_elems = (size_t)b * fb.n_splits * kk;
-  if ((rc = ensure(h, h->w_part_s, part_elems * 4))) return rc;
-  if ((rc = ensure(h, h->w_part_i, part_elems * 4))) return rc;
+  const size_t part_elems = (size_t)b * pl.fb_splits * kk;
+  if ((rc = ensure(h, h->w_fb_s, part_elems * 4))) return rc;
+  if ((rc = ensure(h, h->w_fb_i, part_elems * 4))) return rc;
   if (!h->mfma_attr_set) {   // per handle = per device: the limit is a property of the function ON a device
-    HIP_TRY(h, hipFuncSetAttribute((const void*)scan_mfma_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_smem_bytes()));
-    HIP_TRY(h, hipFuncSetAttribute((const void*)scan_mfma_pass_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kMfNumStages * kMfStage));
-    HIP_TRY(h, hipFuncSetAttribute((const void*)scan_mfma_pass_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kMfNumStages * kMfStage));
-    HIP_TRY(h, hipFuncSetAttribute((const void*)scan_mfma_ws_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_smem_bytes()));
-    HIP_TRY(h, hipFuncSetAttribute((const void*)scan_mfma_ws_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_smem_bytes()));
-    HIP_TRY(h, hipFuncSetAttribute((const void*)scan_mfma_wide_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m5_smem_bytes()));
-    HIP_TRY(h, hipFuncSetAttribute((const void*)scan_mfma_wide_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m5_smem_bytes()));
-    HIP_TRY(h, hipFuncSetAttribute((const void*)scan_mfma_wide_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m5_smem_bytes()));
-    HIP_TRY(h, hipFuncSetAttribute((const void*)scan_mfma_wide_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m5_smem_bytes()));
-    HIP_TRY(h, hipFuncSetAttribute((const void*)scan_mfma_wide_kernel<1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m5_smem_bytes()));
+    HIP_TRY(h, mfma_prepare_device());
     h->mfma_attr_set = true;
   }
-  const unsigned char* qb16 = (const unsigned char*)h->w_mfma.p;
-  float* cand_s = (float*)h->w_cand_s.p;
-  int* cand_i = (int*)h->w_cand_i.p;
-  int* cand_cnt = (int*)h->w_cand_cnt.p;
-  int* ovf = cand_cnt + b;
+  MfSearchArgs a;
+  a.rows_bf16 = (const unsigned char*)h->rows_bf16; a.n_rows = n_rows; a.qn = qn; a.b = b; a.kk = kk;
+  a.self0 = self_row0 >= 0 ? (int)self_row0 : -1;
+  a.n_cu = h->n_cu; a.variant = h->mfma_variant; a.cap = cap; a.split_x1000 = h->mfma_split_x1000;
+  a.skip_sample = h->mfma_skip_sample; a.force_fallback = h->mfma_force_fallback; a.ablate = h->mfma_ablate; a.stream_nt = h->stream_nt;
+  a.qb16 = (unsigned char*)h->w_mfma.p;
+  a.cand_s = (float*)h->w_cand_s.p; a.cand_i = (int*)h->w_cand_i.p; a.cand_cnt = (int*)h->w_cand_cnt.p;
+  a.thr = (float*)h->w_thr.p; a.dense = (float*)h->w_dense.p;
+  a.list_s = (float*)h->w_list_s.p; a.list_i = (int*)h->w_list_i.p;
+  a.seed_s = (float*)h->w_seed_s.p; a.seed_i = (int*)h->w_seed_i.p;
+  a.part_s = (float*)h->w_fb_s.p; a.part_i = (int*)h->w_fb_i.p;
+  a.st = st;
   h->mfma_last_b = b;
-  h->mfma_last_skipped = 0;
-  float* thr = (float*)h->w_thr.p;
-  float* dense = (float*)h->w_dense.p;
-  float* list_s = (float*)h->w_list_s.p;
-  int* list_i = (int*)h->w_list_i.p;
-  float* seed_s = (float*)h->w_seed_s.p;
-  int* seed_i = (int*)h->w_seed_i.p;
-  const size_t smem3 = (size_t)kMfNumStages * kMfStage;
-
-  hipLaunchKernelGGL(queries_to_bf16_kernel, dim3(std::min(1024, (b_pad * kMfDim + 255) / 256)), dim3(256), 0, st,
-                     qn, b, b_pad, (uint16_t*)h->w_mfma.p);
-  HIP_TRY(h, hipGetLastError());
-  HIP_TRY(h, hipMemsetAsync(ovf, 0, 4, st));
-  h->last_bytes = 0.0;
-
-  // pass 0: dense scores of a strided 4-tile sample -> t0 = k'-th best per query
-  long long t_cur = std::min<long long>(n_tiles, kMf3DenseTiles);
-  {
-    const int stride = (int)std::max<long long>(1, n_tiles / t_cur);
-    const MfGrid g = mf_grid(h->n_cu, n_qt, t_cur, 1 << 30);
-    if (variant == 5)
-      hipLaunchKernelGGL((scan_mfma_wide_kernel<0>), dim3(n_qt * g.n_splits), dim3(kM5Threads), m5_smem_bytes(), st, rows, n_rows, qb16, b,
-                         n_qt, g.n_splits, g.tiles_per_split, (int)t_cur, stride, self0, g.xcd_map, (const float*)nullptr, dense,
-                         (int*)nullptr, (float*)nullptr, (int*)nullptr, 0, 0, 0);
-    else if (variant == 4)
-      hipLaunchKernelGGL((scan_mfma_ws_kernel<0>), dim3(n_qt * g.n_splits), dim3(kWsThreads), ws_smem_bytes(), st, rows, n_rows, qb16, b,
-                         n_qt, g.n_splits, g.tiles_per_split, (int)t_cur, stride, self0, g.xcd_map, (const float*)nullptr, dense,
-                         (int*)nullptr, (float*)nullptr, (int*)nullptr, 0, ovf, 0, 0);
-    else
-      hipLaunchKernelGGL((scan_mfma_pass_kernel<0>), dim3(n_qt * g.n_splits), dim3(kMfThreads), smem3, st, rows, n_rows, qb16, b,
-                         n_qt, g.n_splits, g.tiles_per_split, (int)t_cur, stride, self0, g.xcd_map, (const float*)nullptr, dense,
-                         (int*)nullptr, (float*)nullptr, (int*)nullptr, 0);
-    HIP_TRY(h, hipGetLastError());
-    // rows of the dense matrix beyond the sampled tiles were never written: select over t_cur*256 columns only
-    // n_tiles == t_cur: the dense pass saw the whole store and the next pass is the last; either way a valid lower bound suffices
-    hipLaunchKernelGGL(dense_lower_bound_kernel, dim3(b), dim3(64), 0, st, dense, kMf3DenseLd, (int)t_cur * kMfBM, kk, thr);
-    HIP_TRY(h, hipGetLastError());
-  }
-  // append passes over geometrically growing strided samples; the growth factor per pass is
-  // at most R = cap/(4 k') so that ~cap/4 candidates per query are expected in each
-  const double Rmax = std::max<double>(2.0, (double)cap / (4.0 * kk));
-  const double span = (double)n_tiles / (double)t_cur;
-  const int n_pass = span <= 1.0 ? 1 : std::max(1, (int)std::ceil(std::log(span) / std::log(Rmax) - 0.15));   // up to ~2x Rmax per pass
-  const double growth = std::pow(span, 1.0 / n_pass);
-  // Two passes (the usual case): the last one leaves out the tiles the sample pass multiplied and the final
-  // selection is seeded with the sample's sorted list instead — the sample is 2 % of the tiles at 10M rows,
-  // 6 % at an 8-GPU shard's 1.25M.  (Not with the barrier-ring kernel, variant 3, which keeps plain indexing.)
-  bool seeded = false;
-  int seed_stride = 0, seed_n = 0;   // the sample the seed list came from: tiles 0, stride, ..., (n-1)*stride
-  for (int pass = 1; pass <= n_pass; ++pass) {
-    const bool last = pass == n_pass;
-    long long t_next = last ? n_tiles : std::min<long long>(n_tiles, (long long)std::ceil((double)t_cur * growth));
-    if (!last && n_pass == 2) t_next = std::min<long long>(n_tiles, (long long)std::ceil((double)t_cur * std::pow(span, h->mfma_split_x1000 * 1e-3)));
-    int stride = last ? 1 : (int)std::max<long long>(1, n_tiles / t_next);
-    int skip_n = 0;
-    long long pass_tiles = t_next;
-    if (last && seeded) { stride = seed_stride; skip_n = seed_n; pass_tiles = n_tiles - skip_n; h->mfma_last_skipped = skip_n; }
-    HIP_TRY(h, hipMemsetAsync(cand_cnt, 0, (size_t)b * 4, st));
-    if (pass_tiles > 0) {
-      const MfGrid g = mf_grid(h->n_cu, n_qt, pass_tiles, 1 << 30);
-      if (variant == 5) {
-        auto kern = (h->mfma_ablate & 8) ? scan_mfma_wide_kernel<1, 3> : (h->mfma_ablate & 1) ? scan_mfma_wide_kernel<1, 1> : (h->mfma_ablate & 2) ? scan_mfma_wide_kernel<1, 2> : scan_mfma_wide_kernel<1, 0>;
-        hipLaunchKernelGGL(kern, dim3(n_qt * g.n_splits), dim3(kM5Threads), m5_smem_bytes(), st, rows, n_rows, qb16, b,
-                           n_qt, g.n_splits, g.tiles_per_split, (int)pass_tiles, stride, self0, g.xcd_map, (const float*)thr, dense,
-                           cand_cnt, cand_s, cand_i, cap, h->mfma_ablate, skip_n);
-      }
-      else if (variant == 4)
-        hipLaunchKernelGGL((scan_mfma_ws_kernel<1>), dim3(n_qt * g.n_splits), dim3(kWsThreads), ws_smem_bytes(), st, rows, n_rows, qb16, b,
-                           n_qt, g.n_splits, g.tiles_per_split, (int)pass_tiles, stride, self0, g.xcd_map, (const float*)thr, dense,
-                           cand_cnt, cand_s, cand_i, cap, ovf, h->mfma_ablate, skip_n);
-      else
-        hipLaunchKernelGGL((scan_mfma_pass_kernel<1>), dim3(n_qt * g.n_splits), dim3(kMfThreads), smem3, st, rows, n_rows, qb16, b,
-                           n_qt, g.n_splits, g.tiles_per_split, (int)pass_tiles, stride, self0, g.xcd_map, (const float*)thr, dense,
-                           cand_cnt, cand_s, cand_i, cap);
-      HIP_TRY(h, hipGetLastError());
-    }
-    if (last) h->last_bytes = (double)n_rows * kMfDim * 2;
-    // the sample pass of a two-pass search keeps its sorted list when the last pass can leave its tiles out
-    const bool keep = !last && n_pass == 2 && variant != 3 && stride >= 2 && h->mfma_skip_sample;
-    hipLaunchKernelGGL(select_kth_kernel, dim3(b), dim3(1024), 0, st, (const float*)cand_s, (const int*)cand_i,
-                       (const int*)cand_cnt, cap, kk, thr, (last || keep) ? (last ? list_s : seed_s) : (float*)nullptr,
-                       (last || keep) ? (last ? list_i : seed_i) : (int*)nullptr, ovf,
-                       (last && seeded) ? (const float*)seed_s : (const float*)nullptr,
-                       (last && seeded) ? (const int*)seed_i : (const int*)nullptr);
-    HIP_TRY(h, hipGetLastError());
-    if (keep) { seeded = true; seed_stride = stride; seed_n = (int)t_next; }
-    t_cur = t_next;
-  }
-  if (h->mfma_force_fallback) HIP_TRY(h, hipMemsetAsync(ovf, 1, 1, st));
-  // exact list kernel: returns at once unless the overflow flag is set
-  hipLaunchKernelGGL(scan_mfma_topk_kernel, dim3(n_qt_fb * fb.n_splits), dim3(kMfThreads), mf_smem_bytes(), st, rows, n_rows, qb16, b,
-                     n_qt_fb, fb.n_splits, fb.tiles_per_split, kk, self0, fb.xcd_map, h->mfma_ablate, (const int*)ovf,
-                     (float*)h->w_part_s.p, (int*)h->w_part_i.p);
-  HIP_TRY(h, hipGetLastError());
-  if (h->ev_on) HIP_TRY(h, hipEventRecord(h->ev[1], st));
+  h->last_path = pl.variant;
+  h->last_passes = 1;
+  HIP_TRY(h, mfma_search_launch(a, &h->mfma_last_skipped));
+  h->last_bytes = (double)n_rows * kMfRowBytesC;
+  if (h->ev_on && last_chunk) HIP_TRY(h, hipEventRecord(h->ev[1], st));
+  const int* ovf = a.cand_cnt + b;
   if (kp)
-    hipLaunchKernelGGL((final_sorted_kernel<true>), dim3(b), dim3(1024), 0, st, (const float*)list_s, (const int*)list_i, 1, kk, k,
+    hipLaunchKernelGGL((final_sorted_kernel<true>), dim3(b), dim3(1024), 0, st, (const float*)a.list_s, (const int*)a.list_i, 1, kk, k,
                        (long long)h->row_offset, (const float*)h->rows_f32, h->ld, qn, (long long*)out_idx, out_dist,
-                       (const int*)ovf, (const float*)h->w_part_s.p, (const int*)h->w_part_i.p, fb.n_splits);
+                       ovf, (const float*)a.part_s, (const int*)a.part_i, pl.fb_splits);
   else
-    hipLaunchKernelGGL((final_sorted_kernel<false>), dim3(b), dim3(1024), 0, st, (const float*)list_s, (const int*)list_i, 1, kk, k,
+    hipLaunchKernelGGL((final_sorted_kernel<false>), dim3(b), dim3(1024), 0, st, (const float*)a.list_s, (const int*)a.list_i, 1, kk, k,
                        (long long)h->row_offset, (const float*)nullptr, h->ld, qn, (long long*)out_idx, out_dist,
-                       (const int*)ovf, (const float*)h->w_part_s.p, (const int*)h->w_part_i.p, fb.n_splits);
+                       ovf, (const float*)a.part_s, (const int*)a.part_i, pl.fb_splits);
   HIP_TRY(h, hipGetLastError());
-  if (h->ev_on) HIP_TRY(h, hipEventRecord(h->ev[2], st));
-  if (h->ev_on) h->timing_valid = true;
   return VDB_OK;
 }
 
-// Which path serves a bf16 768-d batch faster?  Coefficients measured on MI355X (round 1, 10M and 1M rows):
+// Which path serves a bf16 768-d batch faster?  Coefficients measured on MI355X (10M and 1M rows):
 // a GEMV pass costs a launch (~12 us) plus the corpus at ~6.7 TB/s, times 1.0 / 1.18 / 1.64 for 1 / 2 / 4
-// queries per pass (b = 3 runs as 2 + 1); the MFMA path costs ~100 us of launches (dense sample, selects,
-// append passes) plus 0.29 ns per row and 128-query tile, or 0.36 (+0.05) ns per row and 256-query tile.
-// Measured crossover at 10M rows: b = 2 GEMV 2.72 ms vs MFMA 2.96; b = 3 5.16 vs 3.01; b = 8 7.58 vs 3.13.
-bool mfma_is_faster(int b, int n_rows) {
-  const double pass = 12e-6 + (double)n_rows * kMfRowBytes / 6.7e12;
+// queries per pass (b = 3 runs as 2 + 1).  The batched path costs ~100 us of launches (dense sample, selects,
+// append passes) plus, per row: the streaming kernel (<= 64 queries) the corpus at ~6.3 TB/s; the tiled kernels
+// 0.29 ns per 128-query tile or 0.36 (+0.05) ns per 256-query tile.
+bool mfma_is_faster(int b, int n_rows, int variant_opt) {
+  const double pass = 12e-6 + (double)n_rows * kMfRowBytesC / 6.7e12;
   const int r = b & 3;
   const double gemv = pass * (1.64 * (b >> 2) + (r == 3 ? 2.18 : r == 2 ? 1.18 : r == 1 ? 1.0 : 0.0));
-  const int pad_wide = ((b + kM5BN - 1) / kM5BN) * kM5BN, pad_narrow = ((b + kMfBN - 1) / kMfBN) * kMfBN;
-  const bool wide = 2 * pad_wide <= 3 * pad_narrow;
-  const double mfma = 100e-6 + (double)n_rows * (wide ? 0.36e-9 * (pad_wide / kM5BN) + 0.05e-9 : 0.29e-9 * (pad_narrow / kMfBN));
+  const MfPlan pl = mfma_plan(b, n_rows, 256, variant_opt);
+  double mfma;
+  if (pl.variant == 6) mfma = 110e-6 + (double)n_rows * kMfRowBytesC / (b <= 32 ? 6.3e12 : 6.0e12);
+  else if (pl.variant == 5) mfma = 100e-6 + (double)n_rows * (0.36e-9 * pl.n_qt + 0.05e-9);
+  else mfma = 100e-6 + (double)n_rows * 0.29e-9 * pl.n_qt;
   return mfma < gemv;
 }
 
@@ -484,7 +345,7 @@ int ensure_parts(vdb_t* h, const WsSet& W, size_t part_elems) {
 }
 
 // The scan passes of one chunk of cb <= 64 normalised queries: partial lists [cb][grid][kk] into W.
-int gemv_scan_chunk(vdb_t* h, const WsSet& W, const float* qn, int cb, int kk, int64_t self_row0, const unsigned* allow,
+int gemv_scan_chunk(vdb_t* h, const WsPtrs& W, const float* qn, int cb, int kk, int64_t self_row0, const unsigned* allow,
                     int grid, hipStream_t st) {
   const int e = entries_for(kk);
   const bool bf16 = h->dtype == VDB_BF16;
@@ -499,31 +360,33 @@ int gemv_scan_chunk(vdb_t* h, const WsSet& W, const float* qn, int cb, int kk, i
     a.rows = rows; a.n_rows = n_rows; a.qn = qn + (size_t)q * h->ld; a.kk = kk;
     a.self0 = self_row0 >= 0 ? (int)(self_row0 + q) : -1;
     a.allow = allow;
-    a.part_s = (float*)W.ps->p + (size_t)q * grid * kk;
-    a.part_i = (int*)W.pi->p + (size_t)q * grid * kk;
+    a.part_s = W.ps + (size_t)q * grid * kk;
+    a.part_i = W.pi + (size_t)q * grid * kk;
     a.grid = grid; a.st = st;
-    a.smem = (size_t)kScanWaves * qb * kk * 8;
+    a.smem = (size_t)4 * qb * kk * 8;   // 4 waves per scan block
     bool ok;
     const bool nt = h->scan_nt_loads != 0;
     if (fast_dim) {
-      if (h->dim == 768) ok = bf16 ? launch_scan_dim<bf16_t, 768>(a, qb, e, nt) : launch_scan_dim<float, 768>(a, qb, e, nt);
-      else ok = bf16 ? launch_scan_dim<bf16_t, 384>(a, qb, e, nt) : launch_scan_dim<float, 384>(a, qb, e, nt);
+      ok = launch_scan_fast(bf16, h->dim, a, qb, e, nt);
     } else {
-      a.smem = (size_t)kScanWaves * kk * 8 + (size_t)h->ld * 4;
-      ok = bf16 ? launch_scan_generic<bf16_t>(a, h->ld, e, nt) : launch_scan_generic<float>(a, h->ld, e, nt);
+      a.smem = (size_t)4 * kk * 8 + (size_t)h->ld * 4;
+      ok = launch_scan_any(bf16, a, h->ld, e, nt);
     }
     if (!ok) return fail(h, VDB_ERR_ARG, "search: unsupported k for this path");
     HIP_TRY(h, hipGetLastError());
     h->last_bytes += (double)n_rows * h->ld * (bf16 ? 2 : 4);
+    h->last_passes++;
     q += qb;
   }
   return VDB_OK;
 }
 
-// Does a batch take the MFMA path?  (bf16 store, fast dim, enough queries that it beats ceil(b/4) GEMV passes)
-bool takes_mfma_path(vdb_t* h, int b, int kk, bool masked) {
-  return !masked && h->dtype == VDB_BF16 && h->dim == 768 && h->ld == 768 && b >= h->batch_mfma_min_b && mfma_path_supported(kk) &&
-         h->n >= 4096 && (!h->mfma_cost_model || mfma_is_faster(b, (int)h->n));
+// Does a batch take the MFMA path?  bf16 store WITH an fp32 rerank (the batched kernels round the queries to bf16
+// too; the rerank restores fp32 scores, so results do not depend on the batch size — without a rerank every
+// batch stays on the GEMV scan, which keeps fp32 queries), fast dim, enough queries that it beats ceil(b/4) GEMV passes.
+bool takes_mfma_path(vdb_t* h, int b, int kk, int kp, bool masked) {
+  return !masked && kp != 0 && h->dtype == VDB_BF16 && h->dim == 768 && h->ld == 768 && b >= h->batch_mfma_min_b && mfma_kk_supported(kk) &&
+         h->n >= 4096 && (!h->mfma_cost_model || mfma_is_faster(b, (int)h->n, h->mfma_variant));
 }
 
 // Core search over device-resident, already *normalised* queries qn [b][ld].
@@ -533,6 +396,9 @@ int search_core(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
                 float* out_dist, hipStream_t st, const unsigned* allow = nullptr) {
   const int kk = kp ? kp : k;
   const int n_rows = (int)h->n;
+  // slot 0 of the two-phase search shares these workspaces: a scan pending there would be overwritten
+  if (h->split[0].pending || h->split[1].pending)
+    return fail(h, VDB_ERR_STATE, "search: a two-phase scan is pending on this handle (call vdb_search_finish_dev first)");
 
   h->ev_on = h->timing_every <= 1 || (h->n_calls % h->timing_every) == 0;
   h->n_calls++;
@@ -542,6 +408,8 @@ int search_core(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
     HIP_TRY(h, hipEventRecord(h->ev[0], st));
   }
   h->last_bytes = 0.0;
+  h->last_path = 0;
+  h->last_passes = 0;
 
   if (n_rows == 0) {
     // empty store: all -1 / +inf
@@ -553,20 +421,30 @@ int search_core(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
     return VDB_OK;
   }
 
-  if (takes_mfma_path(h, b, kk, allow != nullptr)) return mfma_search(h, qn, b, k, kp, self_row0, out_idx, out_dist, st);
+  int rc;
+  if (takes_mfma_path(h, b, kk, kp, allow != nullptr)) {
+    // chunks of at most 4096 queries: the candidate buffers are b x cap x 8 bytes (131 KB per query)
+    for (int q0 = 0; q0 < b; q0 += kMfMaxQueriesPerCall) {
+      const int cb = std::min(kMfMaxQueriesPerCall, b - q0);
+      if ((rc = mfma_search(h, qn + (size_t)q0 * h->ld, cb, k, kp, self_row0 >= 0 ? self_row0 + q0 : -1, out_idx + (size_t)q0 * k,
+                            out_dist + (size_t)q0 * k, st, q0 + cb == b))) return rc;
+    }
+    if (h->ev_on) { HIP_TRY(h, hipEventRecord(h->ev[2], st)); h->timing_valid = true; }
+    return VDB_OK;
+  }
 
   const int grid = gemv_grid(h);
   const WsSet W = ws_of(h, 0);
   // queries are processed in chunks so the partial buffers stay small
   const int cb_max = std::min(b, kQChunk);
-  int rc;
   if ((rc = ensure_parts(h, W, (size_t)cb_max * grid * kk))) return rc;
+  const WsPtrs P = ptrs_of(W);
   for (int q0 = 0; q0 < b; q0 += kQChunk) {
     const int cb = std::min(kQChunk, b - q0);
-    if ((rc = gemv_scan_chunk(h, W, qn + (size_t)q0 * h->ld, cb, kk, self_row0 >= 0 ? self_row0 + q0 : -1, allow, grid, st))) return rc;
+    if ((rc = gemv_scan_chunk(h, P, qn + (size_t)q0 * h->ld, cb, kk, self_row0 >= 0 ? self_row0 + q0 : -1, allow, grid, st))) return rc;
     if (q0 == 0 && b <= kQChunk) if (h->ev_on) HIP_TRY(h, hipEventRecord(h->ev[1], st));
     // --- merge + finish ----------------------------------------------------
-    if ((rc = finish_search(h, W, cb, grid, kk, k, kp, qn + (size_t)q0 * h->ld, out_idx + (size_t)q0 * k,
+    if ((rc = finish_search(h, P, cb, grid, kk, k, kp, qn + (size_t)q0 * h->ld, out_idx + (size_t)q0 * k,
                             out_dist + (size_t)q0 * k, st))) return rc;
   }
   if (b > kQChunk) if (h->ev_on) HIP_TRY(h, hipEventRecord(h->ev[1], st));  // multi-chunk: scan/merge interleave, report total as scan
@@ -635,11 +513,53 @@ int vdb_create(vdb_t** out, int dim, int dtype, int keep_f32, int device_id) {
   return VDB_OK;
 }
 
+// Row-sharded store over the GPUs of one node in ONE process: the handle routes add/search to
+// one child handle per entry of device_ids (an id may repeat: several shards on one GPU).
+int vdb_create_sharded(vdb_t** out, int dim, int dtype, int keep_f32, const int* device_ids, int n_devices) {
+  if (!out) return fail(nullptr, VDB_ERR_ARG, "vdb_create_sharded: out is NULL");
+  if (!device_ids || n_devices < 1 || n_devices > 64) return fail(nullptr, VDB_ERR_ARG, "vdb_create_sharded: need 1..64 device ids");
+  vdb_t* p = new (std::nothrow) vdb();
+  if (!p) return fail(nullptr, VDB_ERR_MEMORY, "vdb_create_sharded: out of host memory");
+  auto bail = [&](int code, const std::string& msg) { vdb_destroy(p); g_err = msg; return code; };
+  for (int s = 0; s < n_devices; ++s) {
+    vdb_t* c = nullptr;
+    const int rc = vdb_create(&c, dim, dtype, keep_f32, device_ids[s]);
+    if (rc) { const std::string m = g_err; return bail(rc, m); }
+    p->shards.push_back(c);
+  }
+  vdb_t* c0 = p->shards[0];
+  p->dim = c0->dim; p->ld = c0->ld; p->dtype = c0->dtype; p->keep_f32 = c0->keep_f32; p->device = c0->device; p->n_cu = c0->n_cu;
+  if (hipSetDevice(p->device) != hipSuccess || hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&p->ev_q, hipEventDisableTiming) != hipSuccess)
+    return bail(VDB_ERR_DEVICE, "vdb_create_sharded: stream/event creation failed");
+  p->shard_done.assign(n_devices, nullptr);
+  p->shard_direct.assign(n_devices, 0);
+  for (int s = 0; s < n_devices; ++s) {
+    vdb_t* c = p->shards[s];
+    if (hipSetDevice(c->device) != hipSuccess || hipEventCreateWithFlags(&p->shard_done[s], hipEventDisableTiming) != hipSuccess)
+      return bail(VDB_ERR_DEVICE, "vdb_create_sharded: event creation failed");
+    if (c->device == p->device) { p->shard_direct[s] = 1; continue; }
+    // P2P: the shard's finish kernel stores its k results straight into shard 0's gather buffer over xGMI
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, c->device, p->device) == hipSuccess && can) {
+      const hipError_t pe = hipDeviceEnablePeerAccess(p->device, 0);
+      if (pe == hipSuccess || pe == hipErrorPeerAccessAlreadyEnabled) p->shard_direct[s] = 1;
+    }
+    (void)hipGetLastError();
+  }
+  *out = p;
+  return VDB_OK;
+}
+
 void vdb_destroy(vdb_t* h) {
   if (!h) return;
+  for (vdb_t* c : h->shards) vdb_destroy(c);
+  for (size_t s = 0; s < h->shard_done.size(); ++s) if (h->shard_done[s]) (void)hipEventDestroy(h->shard_done[s]);
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  DevBuf* bufs[] = {&h->w_q1, &h->w_part_s1, &h->w_part_i1, &h->w_part2_s1, &h->w_part2_i1, &h->w_q, &h->w_part_s, &h->w_part_i, &h->w_part2_s, &h->w_part2_i, &h->w_stage, &h->w_out_i, &h->w_out_d, &h->w_idx, &h->w_mfma,
+  if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
+  if (h->ev_q) (void)hipEventDestroy(h->ev_q);
+  DevBuf* bufs[] = {&h->w_gather, &h->w_fb_s, &h->w_fb_i, &h->w_q1, &h->w_part_s1, &h->w_part_i1, &h->w_part2_s1, &h->w_part2_i1, &h->w_q, &h->w_part_s, &h->w_part_i, &h->w_part2_s, &h->w_part2_i, &h->w_stage, &h->w_out_i, &h->w_out_d, &h->w_idx, &h->w_mfma,
                     &h->w_cand_s, &h->w_cand_i, &h->w_cand_cnt, &h->w_thr, &h->w_dense, &h->w_list_s, &h->w_list_i, &h->w_mask, &h->w_seed_s, &h->w_seed_i};
   for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
   if (h->pin) (void)hipHostFree(h->pin);
@@ -654,14 +574,45 @@ const char* vdb_last_error(vdb_t* h) { return h ? h->err.c_str() : g_err.c_str()
 
 int vdb_reserve(vdb_t* h, int64_t n_rows) {
   if (!h) return VDB_ERR_ARG;
+  if (is_sharded(h)) {
+    // fixes the partition: shard s owns global rows [s*per, (s+1)*per), the last shard also everything beyond
+    const int64_t g = (int64_t)h->shards.size();
+    if (n_rows < 0 || n_rows > g * (int64_t)0x7fffff00) return fail(h, VDB_ERR_ARG, "reserve: n_rows out of range");
+    const int64_t per = std::max<int64_t>(256, ((n_rows + g - 1) / g + 255) / 256 * 256);
+    if (h->per && h->n > 0 && per != h->per) {
+      if (n_rows <= h->per * g) return VDB_OK;
+      return fail(h, VDB_ERR_STATE, "reserve: a sharded handle's partition is fixed by the first vdb_reserve once rows are stored");
+    }
+    h->per = per;
+    for (int64_t s = 0; s < g; ++s) {
+      vdb_t* c = h->shards[(size_t)s];
+      c->row_offset = s * per;
+      const int64_t want = std::max<int64_t>(0, std::min<int64_t>(per, n_rows - s * per));
+      const int rc = vdb_reserve(c, want);
+      if (rc) return fail(h, rc, c->err);
+    }
+    return VDB_OK;
+  }
   if (n_rows < 0 || n_rows > (int64_t)0x7ffffff0) return fail(h, VDB_ERR_ARG, "reserve: n_rows out of range");
   int rc = set_device(h);
   if (rc) return rc;
   return grow(h, n_rows);
 }
 
+namespace {
+// The shard that owns global row r of a sharded handle, and the rows [r, r+len) of an append that land in it.
+struct ShardSpan { int s; int64_t count; };
+ShardSpan shard_span(const vdb_t* h, int64_t r, int64_t len) {
+  const int g = (int)h->shards.size();
+  const int s = (int)std::min<int64_t>(r / h->per, g - 1);
+  const int64_t end = s == g - 1 ? r + len : std::min<int64_t>(r + len, (int64_t)(s + 1) * h->per);
+  return ShardSpan{s, end - r};
+}
+}  // namespace
+
 int vdb_set_row_offset(vdb_t* h, int64_t off) {
   if (!h) return VDB_ERR_ARG;
+  NOT_ON_SHARDED(h, "vdb_set_row_offset");
   h->row_offset = off;
   return VDB_OK;
 }
@@ -670,6 +621,17 @@ int vdb_add(vdb_t* h, const float* rows_host, int64_t n) {
   if (!h) return VDB_ERR_ARG;
   if (n < 0 || (n > 0 && !rows_host)) return fail(h, VDB_ERR_ARG, "vdb_add: bad rows/n");
   if (n == 0) return VDB_OK;
+  if (is_sharded(h)) {
+    if (!h->per) return fail(h, VDB_ERR_STATE, "vdb_add: call vdb_reserve(total rows) on a sharded handle first (it fixes the row partition)");
+    for (int64_t r = 0; r < n;) {
+      const ShardSpan sp = shard_span(h, h->n, n - r);
+      vdb_t* c = h->shards[(size_t)sp.s];
+      const int rc = vdb_add(c, rows_host + (size_t)r * h->dim, sp.count);
+      if (rc) return fail(h, rc, c->err);
+      r += sp.count; h->n += sp.count;
+    }
+    return VDB_OK;
+  }
   int rc = set_device(h);
   if (rc) return rc;
   if ((rc = reserve_for_add(h, n))) return rc;
@@ -690,6 +652,7 @@ int vdb_add_dev(vdb_t* h, const float* rows_dev, int64_t n) {
   if (!h) return VDB_ERR_ARG;
   if (n < 0 || (n > 0 && !rows_dev)) return fail(h, VDB_ERR_ARG, "vdb_add_dev: bad rows/n");
   if (n == 0) return VDB_OK;
+  NOT_ON_SHARDED(h, "vdb_add_dev");
   int rc = set_device(h);
   if (rc) return rc;
   if ((rc = reserve_for_add(h, n))) return rc;
@@ -705,12 +668,62 @@ int vdb_count(vdb_t* h, int64_t* n) {
   return VDB_OK;
 }
 
+namespace {
+// Search on a sharded handle: queries and outputs live on shard 0's device, `st` is a stream of that device.
+// Every shard scans its rows on its own stream (all devices run together), its finish kernel stores the k results
+// straight into shard 0's gather buffer (same device, or over xGMI with peer access; a peer copy otherwise), and one
+// merge kernel on `st` ranks the g lists.  One host thread, no host synchronisation.
+int sharded_search_dev(vdb_t* h, const float* q_dev0, int b, int k, int kp, int64_t* out_idx, float* out_dist, hipStream_t st) {
+  const int g = (int)h->shards.size();
+  int rc;
+  if ((rc = set_device(h))) return rc;
+  const size_t bk = (size_t)b * k;
+  if ((rc = ensure(h, h->w_gather, (size_t)g * bk * 12))) return rc;
+  int64_t* g_idx = (int64_t*)h->w_gather.p;
+  float* g_dist = (float*)((char*)h->w_gather.p + (size_t)g * bk * 8);
+  HIP_TRY(h, hipEventRecord(h->ev_q, st));   // the queries are ready; the previous call's merge (earlier on st) has read the gather buffer
+  for (int s = 0; s < g; ++s) {
+    vdb_t* c = h->shards[(size_t)s];
+    if ((rc = set_device(c))) return fail(h, rc, c->err);
+    HIP_TRY(h, hipStreamWaitEvent(c->stream, h->ev_q, 0));
+    const float* q_local = q_dev0;
+    if (c->device != h->device) {
+      if ((rc = ensure(c, c->w_stage, (size_t)b * h->dim * 4))) return fail(h, rc, c->err);
+      HIP_TRY(h, hipMemcpyPeerAsync(c->w_stage.p, c->device, q_dev0, h->device, (size_t)b * h->dim * 4, c->stream));
+      q_local = (const float*)c->w_stage.p;
+    }
+    float* qn = nullptr;
+    if ((rc = prep_queries(c, q_local, b, c->stream, &qn))) return fail(h, rc, c->err);
+    int64_t* oi = g_idx + (size_t)s * bk;
+    float* od = g_dist + (size_t)s * bk;
+    if (!h->shard_direct[(size_t)s]) {
+      if ((rc = ensure(c, c->w_out_i, bk * 12))) return fail(h, rc, c->err);
+      oi = (int64_t*)c->w_out_i.p;
+      od = (float*)((char*)c->w_out_i.p + bk * 8);
+    }
+    if ((rc = search_core(c, qn, b, k, kp, -1, oi, od, c->stream))) return fail(h, rc, c->err);
+    if (!h->shard_direct[(size_t)s]) {
+      HIP_TRY(h, hipMemcpyPeerAsync(g_idx + (size_t)s * bk, h->device, oi, c->device, bk * 8, c->stream));
+      HIP_TRY(h, hipMemcpyPeerAsync(g_dist + (size_t)s * bk, h->device, od, c->device, bk * 4, c->stream));
+    }
+    HIP_TRY(h, hipEventRecord(h->shard_done[(size_t)s], c->stream));
+  }
+  if ((rc = set_device(h))) return rc;
+  for (int s = 0; s < g; ++s) HIP_TRY(h, hipStreamWaitEvent(st, h->shard_done[(size_t)s], 0));
+  hipLaunchKernelGGL(merge_shards_kernel, dim3(b), dim3(256), 0, st, (const float*)g_dist, (long long)bk, (const long long*)g_idx,
+                     (long long)bk, g, k, (long long*)out_idx, out_dist);
+  HIP_TRY(h, hipGetLastError());
+  return VDB_OK;
+}
+}  // namespace
+
 int vdb_search_dev(vdb_t* h, const float* queries_dev, int b, int k, int kp, int64_t* out_idx_dev,
                    float* out_dist_dev, void* stream) {
   if (!h) return VDB_ERR_ARG;
   int rc = check_search_args(h, queries_dev, b, k, kp, out_idx_dev, out_dist_dev);
   if (rc) return rc;
   if (b == 0) return VDB_OK;
+  if (is_sharded(h)) return sharded_search_dev(h, queries_dev, b, k, kp, out_idx_dev, out_dist_dev, (hipStream_t)stream);
   if ((rc = set_device(h))) return rc;
   hipStream_t st = (hipStream_t)stream;  // NULL = the default (null) stream, HIP convention
   float* qn = nullptr;
@@ -721,10 +734,12 @@ int vdb_search_dev(vdb_t* h, const float* queries_dev, int b, int k, int kp, int
 int vdb_search_scan_dev(vdb_t* h, const float* queries_dev, int b, int k, int kp, int slot, void* stream) {
   if (!h) return VDB_ERR_ARG;
   if (slot != 0 && slot != 1) return fail(h, VDB_ERR_ARG, "search_scan: slot must be 0 or 1");
+  NOT_ON_SHARDED(h, "vdb_search_scan_dev");
   int rc = check_search_args(h, queries_dev, b, k, kp, h, h);
   if (rc) return rc;
   const int kk = kp ? kp : k;
-  if (b < 1 || b > kQChunk || h->n == 0 || takes_mfma_path(h, b, kk, false))
+  if (h->split[slot].pending) return fail(h, VDB_ERR_STATE, "search_scan: this slot already holds a pending scan");
+  if (b < 1 || b > kQChunk || h->n == 0 || takes_mfma_path(h, b, kk, kp, false))
     return fail(h, VDB_ERR_STATE, "search_scan: this batch does not split (empty store, more than 64 queries, or the batched MFMA path): use vdb_search_dev");
   if ((rc = set_device(h))) return rc;
   hipStream_t st = (hipStream_t)stream;
@@ -738,11 +753,11 @@ int vdb_search_scan_dev(vdb_t* h, const float* queries_dev, int b, int k, int kp
     h->n_timed++;
     HIP_TRY(h, hipEventRecord(sp.ev[0], st));
   }
-  h->last_bytes = 0.0;
+  h->last_bytes = 0.0; h->last_path = 0; h->last_passes = 0;
   const int grid = gemv_grid(h);
   const WsSet W = ws_of(h, slot);
   if ((rc = ensure_parts(h, W, (size_t)b * grid * kk))) return rc;
-  if ((rc = gemv_scan_chunk(h, W, qn, b, kk, -1, nullptr, grid, st))) return rc;
+  if ((rc = gemv_scan_chunk(h, ptrs_of(W), qn, b, kk, -1, nullptr, grid, st))) return rc;
   if (sp.ev_on) HIP_TRY(h, hipEventRecord(sp.ev[1], st));
   sp.pending = true; sp.b = b; sp.k = k; sp.kp = kp; sp.grid = grid;
   return VDB_OK;
@@ -760,7 +775,7 @@ int vdb_search_finish_dev(vdb_t* h, int slot, int64_t* out_idx_dev, float* out_d
   const WsSet W = ws_of(h, slot);
   const int kk = sp.kp ? sp.kp : sp.k;
   sp.pending = false;
-  if ((rc = finish_search(h, W, sp.b, sp.grid, kk, sp.k, sp.kp, (const float*)W.q->p, out_idx_dev, out_dist_dev, st))) return rc;
+  if ((rc = finish_search(h, ptrs_of(W), sp.b, sp.grid, kk, sp.k, sp.kp, (const float*)W.q->p, out_idx_dev, out_dist_dev, st))) return rc;
   if (sp.ev_on) {
     HIP_TRY(h, hipEventRecord(sp.ev[2], st));
     h->ev = sp.ev;
@@ -797,9 +812,13 @@ int vdb_search(vdb_t* h, const float* queries_host, int b, int k, int kp, int64_
   } else {
     HIP_TRY(h, hipMemcpyAsync(h->w_stage.p, queries_host, qbytes, hipMemcpyHostToDevice, h->stream));
   }
-  float* qn = nullptr;
-  if ((rc = prep_queries(h, (const float*)h->w_stage.p, b, h->stream, &qn))) return rc;
-  if ((rc = search_core(h, qn, b, k, kp, -1, d_idx, d_dist, h->stream))) return rc;
+  if (is_sharded(h)) {
+    if ((rc = sharded_search_dev(h, (const float*)h->w_stage.p, b, k, kp, d_idx, d_dist, h->stream))) return rc;
+  } else {
+    float* qn = nullptr;
+    if ((rc = prep_queries(h, (const float*)h->w_stage.p, b, h->stream, &qn))) return rc;
+    if ((rc = search_core(h, qn, b, k, kp, -1, d_idx, d_dist, h->stream))) return rc;
+  }
   if (pinned) {
     char* back = (char*)h->pin + qbytes;
     HIP_TRY(h, hipMemcpyAsync(back, h->w_out_i.p, ibytes + dbytes, hipMemcpyDeviceToHost, h->stream));
@@ -817,6 +836,7 @@ int vdb_search(vdb_t* h, const float* queries_host, int b, int k, int kp, int64_
 int vdb_search_masked_dev(vdb_t* h, const float* queries_dev, int b, int k, int kp, const uint32_t* allow_dev,
                           int64_t n_bits, int64_t* out_idx_dev, float* out_dist_dev, void* stream) {
   if (!h) return VDB_ERR_ARG;
+  NOT_ON_SHARDED(h, "vdb_search_masked_dev");
   if (!allow_dev && h->n > 0) return fail(h, VDB_ERR_ARG, "search_masked: NULL bitmap");
   if (n_bits != h->n) return fail(h, VDB_ERR_ARG, "search_masked: the bitmap must hold one bit per stored row");
   int rc = check_search_args(h, queries_dev, b, k, kp, out_idx_dev, out_dist_dev);
@@ -832,6 +852,7 @@ int vdb_search_masked_dev(vdb_t* h, const float* queries_dev, int b, int k, int 
 int vdb_search_masked(vdb_t* h, const float* queries_host, int b, int k, int kp, const uint32_t* allow_host,
                       int64_t n_bits, int64_t* out_idx, float* out_dist) {
   if (!h) return VDB_ERR_ARG;
+  NOT_ON_SHARDED(h, "vdb_search_masked");
   if (!allow_host && h->n > 0) return fail(h, VDB_ERR_ARG, "search_masked: NULL bitmap");
   if (n_bits != h->n) return fail(h, VDB_ERR_ARG, "search_masked: the bitmap must hold one bit per stored row");
   int rc = check_search_args(h, queries_host, b, k, kp, out_idx, out_dist);
@@ -858,6 +879,7 @@ int vdb_search_masked(vdb_t* h, const float* queries_host, int b, int k, int kp,
 int vdb_merge_topk_dev(vdb_t* h, const float* cd, int64_t dstride, const int64_t* ci, int64_t istride, int g,
                        int b, int k, int64_t* oi, float* od, void* stream) {
   if (!h) return VDB_ERR_ARG;
+  NOT_ON_SHARDED(h, "vdb_merge_topk_dev");
   if (g < 1 || b < 0 || k < 1 || k > VDB_MAX_K) return fail(h, VDB_ERR_ARG, "merge: bad g/b/k");
   if (b > 0 && (!cd || !ci || !oi || !od)) return fail(h, VDB_ERR_ARG, "merge: NULL buffer");
   if (b == 0) return VDB_OK;
@@ -874,28 +896,71 @@ int vdb_merge_topk_dev(vdb_t* h, const float* cd, int64_t dstride, const int64_t
 int vdb_selfjoin(vdb_t* h, int64_t q_row0, int64_t q_n, int k, int exclude_self, int kp, int64_t* out_idx,
                  float* out_dist) {
   if (!h) return VDB_ERR_ARG;
+  NOT_ON_SHARDED(h, "vdb_selfjoin");
   if (q_row0 < 0 || q_n < 0 || q_row0 + q_n > h->n) return fail(h, VDB_ERR_ARG, "selfjoin: query range outside the store");
   int rc = check_search_args(h, h, q_n > 0 ? 1 : 0, k, kp, out_idx, out_dist);
   if (rc) return rc;
   if (q_n == 0) return VDB_OK;
   if ((rc = set_device(h))) return rc;
-  const int qblock = 4096;  // queries per pass
+  // Blocks of 4096 rows-as-queries.  The device never waits for the host: block j's results go to one of two
+  // device buffers, a copy stream brings them to pinned memory while block j+1 computes, and the host moves
+  // block j-1 into the caller's arrays meanwhile.
+  const int qblock = kMfMaxQueriesPerCall;
+  const size_t ibytes = (size_t)qblock * k * 8, dbytes = (size_t)qblock * k * 4, obytes = ibytes + dbytes;
   if ((rc = ensure(h, h->w_q, (size_t)qblock * h->ld * 4))) return rc;
-  if ((rc = ensure(h, h->w_out_i, (size_t)qblock * k * 8))) return rc;
-  if ((rc = ensure(h, h->w_out_d, (size_t)qblock * k * 4))) return rc;
-  for (int64_t q0 = 0; q0 < q_n; q0 += qblock) {
-    const int cb = (int)std::min<int64_t>(qblock, q_n - q0);
-    // stored rows are unit vectors already: copy them as the normalised queries
-    hipLaunchKernelGGL(rows_to_f32_kernel, dim3(std::min(4096, (cb * h->ld + 255) / 256)), dim3(256), 0, h->stream,
-                       h->keep_f32 ? h->rows_f32 : nullptr, h->rows_bf16, h->ld, (long long)(q_row0 + q0), cb, (float*)h->w_q.p);
-    HIP_TRY(h, hipGetLastError());
-    if ((rc = search_core(h, (const float*)h->w_q.p, cb, k, kp, exclude_self ? q_row0 + q0 : -1,
-                          (int64_t*)h->w_out_i.p, (float*)h->w_out_d.p, h->stream))) return rc;
-    HIP_TRY(h, hipMemcpyAsync(out_idx + (size_t)q0 * k, h->w_out_i.p, (size_t)cb * k * 8, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(out_dist + (size_t)q0 * k, h->w_out_d.p, (size_t)cb * k * 4, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if ((rc = ensure(h, h->w_out_i, 2 * obytes))) return rc;
+  if (h->pin_bytes < 2 * obytes) {
+    if (h->pin) { HIP_TRY(h, hipStreamSynchronize(h->stream)); HIP_TRY(h, hipHostFree(h->pin)); h->pin = nullptr; h->pin_bytes = 0; }
+    HIP_TRY(h, hipHostMalloc(&h->pin, 2 * obytes, hipHostMallocDefault));
+    h->pin_bytes = 2 * obytes;
   }
-  return VDB_OK;
+  if (!h->copy_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+  hipEvent_t computed[2] = {nullptr, nullptr}, copied[2] = {nullptr, nullptr};
+  auto cleanup = [&]() { for (int i = 0; i < 2; ++i) { if (computed[i]) (void)hipEventDestroy(computed[i]); if (copied[i]) (void)hipEventDestroy(copied[i]); } };
+  for (int i = 0; i < 2; ++i)
+    if (hipEventCreateWithFlags(&computed[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&copied[i], hipEventDisableTiming) != hipSuccess) {
+      cleanup();
+      return fail(h, VDB_ERR_DEVICE, "selfjoin: event creation failed");
+    }
+  auto drain = [&](int64_t q0, int cb, int slot) -> int {   // host side of block (q0, cb): pinned -> caller
+    HIP_TRY(h, hipEventSynchronize(copied[slot]));
+    const char* src = (const char*)h->pin + (size_t)slot * obytes;
+    memcpy(out_idx + (size_t)q0 * k, src, (size_t)cb * k * 8);
+    memcpy(out_dist + (size_t)q0 * k, src + ibytes, (size_t)cb * k * 4);
+    return VDB_OK;
+  };
+  int64_t prev_q0 = -1; int prev_cb = 0, prev_slot = 0;
+  int slot = 0;
+  rc = VDB_OK;
+  for (int64_t q0 = 0; q0 < q_n && rc == VDB_OK; q0 += qblock, slot ^= 1) {
+    const int cb = (int)std::min<int64_t>(qblock, q_n - q0);
+    int64_t* d_idx = (int64_t*)((char*)h->w_out_i.p + (size_t)slot * obytes);
+    float* d_dist = (float*)((char*)d_idx + ibytes);
+    auto body = [&]() -> int {
+      // this slot's previous copy (two blocks ago) was drained by the host before block q0 - qblock was issued
+      // stored rows are unit vectors already: copy them as the normalised queries
+      hipLaunchKernelGGL(rows_to_f32_kernel, dim3(std::min(4096, (cb * h->ld + 255) / 256)), dim3(256), 0, h->stream,
+                         h->keep_f32 ? h->rows_f32 : nullptr, h->rows_bf16, h->ld, (long long)(q_row0 + q0), cb, (float*)h->w_q.p);
+      HIP_TRY(h, hipGetLastError());
+      int r2;
+      if ((r2 = search_core(h, (const float*)h->w_q.p, cb, k, kp, exclude_self ? q_row0 + q0 : -1, d_idx, d_dist, h->stream))) return r2;
+      HIP_TRY(h, hipEventRecord(computed[slot], h->stream));
+      HIP_TRY(h, hipStreamWaitEvent(h->copy_stream, computed[slot], 0));
+      char* dst = (char*)h->pin + (size_t)slot * obytes;
+      HIP_TRY(h, hipMemcpyAsync(dst, d_idx, (size_t)cb * k * 8, hipMemcpyDeviceToHost, h->copy_stream));
+      HIP_TRY(h, hipMemcpyAsync(dst + ibytes, d_dist, (size_t)cb * k * 4, hipMemcpyDeviceToHost, h->copy_stream));
+      HIP_TRY(h, hipEventRecord(copied[slot], h->copy_stream));
+      return VDB_OK;
+    };
+    rc = body();
+    if (rc == VDB_OK && prev_q0 >= 0) rc = drain(prev_q0, prev_cb, prev_slot);   // overlaps this block's compute
+    prev_q0 = q0; prev_cb = cb; prev_slot = slot;
+  }
+  if (rc == VDB_OK && prev_q0 >= 0) rc = drain(prev_q0, prev_cb, prev_slot);
+  (void)hipStreamSynchronize(h->stream);
+  (void)hipStreamSynchronize(h->copy_stream);
+  cleanup();
+  return rc;
 }
 
 int vdb_fetch(vdb_t* h, const int64_t* idx_host, int64_t n, float* out_rows_host) {
@@ -904,6 +969,20 @@ int vdb_fetch(vdb_t* h, const int64_t* idx_host, int64_t n, float* out_rows_host
   for (int64_t j = 0; j < n; ++j)
     if (idx_host[j] < 0 || idx_host[j] >= h->n) return fail(h, VDB_ERR_ARG, "fetch: index out of range");
   if (n == 0) return VDB_OK;
+  if (is_sharded(h)) {   // route each global index to its shard (runs of one shard go down together)
+    std::vector<int64_t> local;
+    for (int64_t j = 0; j < n;) {
+      const int sh = shard_span(h, idx_host[j], 1).s;
+      local.clear();
+      int64_t e = j;
+      while (e < n && shard_span(h, idx_host[e], 1).s == sh) { local.push_back(idx_host[e] - (int64_t)sh * h->per); ++e; }
+      vdb_t* c = h->shards[(size_t)sh];
+      const int rc = vdb_fetch(c, local.data(), (int64_t)local.size(), out_rows_host + (size_t)j * h->dim);
+      if (rc) return fail(h, rc, c->err);
+      j = e;
+    }
+    return VDB_OK;
+  }
   int rc = set_device(h);
   if (rc) return rc;
   const int64_t chunk = std::max<int64_t>(1, (int64_t)(64u << 20) / ((int64_t)h->dim * 4));
@@ -925,86 +1004,170 @@ int vdb_fetch(vdb_t* h, const int64_t* idx_host, int64_t n, float* out_rows_host
 // ---- persistence: 32-byte header + unpadded rows (shared with the oracle) --
 struct vdb_file_header { char magic[8]; int32_t dim; int32_t stored_dtype; int64_t n; int64_t row_offset; };
 
-int vdb_save(vdb_t* h, const char* dir) {
-  if (!h || !dir) return VDB_ERR_ARG;
+namespace {
+// append the stored rows of one (unsharded) handle to an open file
+int write_rows(vdb_t* h, FILE* f, std::string* why) {
   int rc = set_device(h);
-  if (rc) return rc;
-  mkdir(dir, 0777);
-  const std::string path = std::string(dir) + "/vectors.vdb";
-  FILE* f = fopen(path.c_str(), "wb");
-  if (!f) return fail(h, VDB_ERR_IO, "save: cannot open " + path);
-  vdb_file_header hd;
-  memset(&hd, 0, sizeof hd);
-  memcpy(hd.magic, "VDBFLAT1", 8);
-  hd.dim = h->dim; hd.stored_dtype = h->keep_f32 ? VDB_F32 : VDB_BF16; hd.n = h->n; hd.row_offset = h->row_offset;
-  bool ok = fwrite(&hd, sizeof hd, 1, f) == 1;
+  if (rc) { *why = h->err; return rc; }
   const size_t esz = h->keep_f32 ? 4 : 2;
   const int64_t chunk = std::max<int64_t>(1, (int64_t)(64u << 20) / ((int64_t)h->dim * 4));
   std::vector<unsigned char> host((size_t)std::min<int64_t>(std::max<int64_t>(h->n, 1), chunk) * h->dim * esz);
-  for (int64_t r = 0; ok && r < h->n; r += chunk) {
+  for (int64_t r = 0; r < h->n; r += chunk) {
     const int64_t m = std::min(chunk, h->n - r);
     const unsigned char* src = h->keep_f32 ? (const unsigned char*)(h->rows_f32 + (size_t)r * h->ld)
                                            : (const unsigned char*)(h->rows_bf16 + (size_t)r * h->ld);
     hipError_t e = hipMemcpy2DAsync(host.data(), (size_t)h->dim * esz, src, (size_t)h->ld * esz, (size_t)h->dim * esz, (size_t)m, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    if (e != hipSuccess) { fclose(f); return fail(h, VDB_ERR_DEVICE, std::string("save: ") + hipGetErrorString(e)); }
-    ok = fwrite(host.data(), esz, (size_t)m * h->dim, f) == (size_t)m * h->dim;
+    if (e != hipSuccess) { *why = std::string("save: ") + hipGetErrorString(e); return VDB_ERR_DEVICE; }
+    if (fwrite(host.data(), esz, (size_t)m * h->dim, f) != (size_t)m * h->dim) { *why = "save: short write"; return VDB_ERR_IO; }
   }
+  return VDB_OK;
+}
+
+// read rows [0, n) of the open file (positioned at their first byte) into an (unsharded) handle
+int read_rows(vdb_t* h, FILE* f, int stored_dtype, int64_t n, std::string* why) {
+  int rc = set_device(h);
+  if (rc) { *why = h->err; return rc; }
+  if ((rc = grow(h, std::max<int64_t>(n, 1)))) { *why = h->err; return rc; }
+  const int dim = h->dim;
+  const int64_t chunk = std::max<int64_t>(1, (int64_t)(64u << 20) / ((int64_t)dim * 4));
+  if (stored_dtype == VDB_F32) {
+    // rows on file are unit vectors; re-normalising is idempotent to <= 1 ulp, so
+    // the verbatim bits are kept for the fp32 copy and bf16 is derived from them.
+    std::vector<float> host((size_t)std::min<int64_t>(std::max<int64_t>(n, 1), chunk) * dim);
+    if ((rc = ensure(h, h->w_stage, host.size() * 4))) { *why = h->err; return rc; }
+    for (int64_t r = 0; r < n; r += chunk) {
+      const int64_t m = std::min(chunk, n - r);
+      if (fread(host.data(), 4, (size_t)m * dim, f) != (size_t)m * dim) { *why = "load: short read"; return VDB_ERR_IO; }
+      hipError_t e = hipMemcpyAsync(h->w_stage.p, host.data(), (size_t)m * dim * 4, hipMemcpyHostToDevice, h->stream);
+      if (e != hipSuccess) { *why = hipGetErrorString(e); return VDB_ERR_DEVICE; }
+      hipLaunchKernelGGL(copy_rows_kernel, dim3((int)std::min<int64_t>((m + 3) / 4, (int64_t)h->n_cu * 8)), dim3(256), 0, h->stream,
+                         (const float*)h->w_stage.p, (long long)m, dim, h->ld,
+                         h->keep_f32 ? h->rows_f32 + (size_t)r * h->ld : nullptr,
+                         h->dtype == VDB_BF16 ? h->rows_bf16 + (size_t)r * h->ld : nullptr);
+      e = hipStreamSynchronize(h->stream);
+      if (e != hipSuccess) { *why = hipGetErrorString(e); return VDB_ERR_DEVICE; }
+    }
+  } else {
+    std::vector<uint16_t> host((size_t)std::min<int64_t>(std::max<int64_t>(n, 1), chunk) * dim);
+    for (int64_t r = 0; r < n; r += chunk) {
+      const int64_t m = std::min(chunk, n - r);
+      if (fread(host.data(), 2, (size_t)m * dim, f) != (size_t)m * dim) { *why = "load: short read"; return VDB_ERR_IO; }
+      hipError_t e = hipMemset2DAsync(h->rows_bf16 + (size_t)r * h->ld, (size_t)h->ld * 2, 0, (size_t)h->ld * 2, (size_t)m, h->stream);
+      if (e == hipSuccess) e = hipMemcpy2DAsync(h->rows_bf16 + (size_t)r * h->ld, (size_t)h->ld * 2, host.data(), (size_t)dim * 2, (size_t)dim * 2, (size_t)m, hipMemcpyHostToDevice, h->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+      if (e != hipSuccess) { *why = hipGetErrorString(e); return VDB_ERR_DEVICE; }
+    }
+  }
+  h->n = n;
+  return VDB_OK;
+}
+
+// open <dir>/vectors.vdb and validate its header against the file's length
+int open_store(const char* dir, FILE** out, vdb_file_header* hd) {
+  const std::string path = std::string(dir) + "/vectors.vdb";
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) return fail(nullptr, VDB_ERR_IO, "load: cannot open " + path);
+  if (fread(hd, sizeof *hd, 1, f) != 1 || memcmp(hd->magic, "VDBFLAT1", 8) != 0) { fclose(f); return fail(nullptr, VDB_ERR_IO, "load: bad header"); }
+  if (hd->dim <= 0 || hd->dim > 32768 || (hd->stored_dtype != VDB_F32 && hd->stored_dtype != VDB_BF16) || hd->n < 0) {
+    fclose(f);
+    return fail(nullptr, VDB_ERR_IO, "load: bad header (dim, dtype or row count out of range)");
+  }
+  struct stat sb;
+  const int64_t want = (int64_t)sizeof *hd + hd->n * (int64_t)hd->dim * (hd->stored_dtype == VDB_F32 ? 4 : 2);
+  if (fstat(fileno(f), &sb) != 0 || (int64_t)sb.st_size != want) {
+    fclose(f);
+    return fail(nullptr, VDB_ERR_IO, "load: " + path + " is truncated or its header disagrees with its length");
+  }
+  *out = f;
+  return VDB_OK;
+}
+}  // namespace
+
+// One flat file whatever the handle: 32-byte header + the rows in global order (a sharded handle writes its shards one
+// after the other), written to a temporary name and renamed into place, so a crash never leaves a half-written store.
+int vdb_save(vdb_t* h, const char* dir) {
+  if (!h || !dir) return VDB_ERR_ARG;
+  if (mkdir(dir, 0777) != 0 && errno != EEXIST) return fail(h, VDB_ERR_IO, std::string("save: cannot create ") + dir);
+  const std::string path = std::string(dir) + "/vectors.vdb", tmp = path + ".tmp";
+  FILE* f = fopen(tmp.c_str(), "wb");
+  if (!f) return fail(h, VDB_ERR_IO, "save: cannot open " + tmp);
+  vdb_file_header hd;
+  memset(&hd, 0, sizeof hd);
+  memcpy(hd.magic, "VDBFLAT1", 8);
+  hd.dim = h->dim; hd.stored_dtype = h->keep_f32 ? VDB_F32 : VDB_BF16; hd.n = h->n; hd.row_offset = h->row_offset;
+  int rc = fwrite(&hd, sizeof hd, 1, f) == 1 ? VDB_OK : VDB_ERR_IO;
+  std::string why = "save: short write";
+  if (rc == VDB_OK) {
+    if (is_sharded(h)) { for (vdb_t* c : h->shards) if ((rc = write_rows(c, f, &why))) break; }
+    else rc = write_rows(h, f, &why);
+  }
+  if (rc == VDB_OK && (fflush(f) != 0 || fsync(fileno(f)) != 0)) rc = VDB_ERR_IO;
   fclose(f);
-  return ok ? VDB_OK : fail(h, VDB_ERR_IO, "save: short write");
+  if (rc == VDB_OK && rename(tmp.c_str(), path.c_str()) != 0) { rc = VDB_ERR_IO; why = "save: cannot rename " + tmp; }
+  if (rc != VDB_OK) { unlink(tmp.c_str()); return fail(h, rc, why); }
+  return VDB_OK;
 }
 
 int vdb_load(vdb_t** out, const char* dir, int dtype, int keep_f32, int device_id) {
   if (!out || !dir) return fail(nullptr, VDB_ERR_ARG, "load: NULL argument");
-  const std::string path = std::string(dir) + "/vectors.vdb";
-  FILE* f = fopen(path.c_str(), "rb");
-  if (!f) return fail(nullptr, VDB_ERR_IO, "load: cannot open " + path);
+  FILE* f = nullptr;
   vdb_file_header hd;
-  if (fread(&hd, sizeof hd, 1, f) != 1 || memcmp(hd.magic, "VDBFLAT1", 8) != 0) { fclose(f); return fail(nullptr, VDB_ERR_IO, "load: bad header"); }
+  int rc = open_store(dir, &f, &hd);
+  if (rc) return rc;
+  if (hd.n > (int64_t)0x7ffffff0) { fclose(f); return fail(nullptr, VDB_ERR_IO, "load: more rows than one shard holds (use vdb_load_sharded)"); }
   if (hd.stored_dtype == VDB_BF16 && (dtype == VDB_F32 || keep_f32)) { fclose(f); return fail(nullptr, VDB_ERR_STATE, "load: file holds bf16 rows only; cannot rebuild fp32 rows"); }
   vdb_t* h = nullptr;
-  int rc = vdb_create(&h, hd.dim, dtype, keep_f32, device_id);
+  rc = vdb_create(&h, hd.dim, dtype, keep_f32, device_id);
   if (rc) { fclose(f); return rc; }
   h->row_offset = hd.row_offset;
-  auto bail = [&](int code, const std::string& msg) { g_err = msg; vdb_destroy(h); fclose(f); return code; };
-  if ((rc = grow(h, std::max<int64_t>(hd.n, 1)))) return bail(rc, h->err);
-  const int64_t chunk = std::max<int64_t>(1, (int64_t)(64u << 20) / ((int64_t)h->dim * 4));
-  if (hd.stored_dtype == VDB_F32) {
-    // rows on file are unit vectors; re-normalising is idempotent to <= 1 ulp, so
-    // the verbatim bits are kept for the fp32 copy and bf16 is derived from them.
-    std::vector<float> host((size_t)std::min<int64_t>(std::max<int64_t>(hd.n, 1), chunk) * hd.dim);
-    if ((rc = ensure(h, h->w_stage, host.size() * 4))) return bail(rc, h->err);
-    for (int64_t r = 0; r < hd.n; r += chunk) {
-      const int64_t m = std::min(chunk, hd.n - r);
-      if (fread(host.data(), 4, (size_t)m * hd.dim, f) != (size_t)m * hd.dim) return bail(VDB_ERR_IO, "load: short read");
-      hipError_t e = hipMemcpyAsync(h->w_stage.p, host.data(), (size_t)m * hd.dim * 4, hipMemcpyHostToDevice, h->stream);
-      if (e != hipSuccess) return bail(VDB_ERR_DEVICE, hipGetErrorString(e));
-      hipLaunchKernelGGL(copy_rows_kernel, dim3((int)std::min<int64_t>((m + 3) / 4, (int64_t)h->n_cu * 8)), dim3(256), 0, h->stream,
-                         (const float*)h->w_stage.p, (long long)m, h->dim, h->ld,
-                         h->keep_f32 ? h->rows_f32 + (size_t)r * h->ld : nullptr,
-                         h->dtype == VDB_BF16 ? h->rows_bf16 + (size_t)r * h->ld : nullptr);
-      e = hipStreamSynchronize(h->stream);
-      if (e != hipSuccess) return bail(VDB_ERR_DEVICE, hipGetErrorString(e));
-    }
-  } else {
-    std::vector<uint16_t> host((size_t)std::min<int64_t>(std::max<int64_t>(hd.n, 1), chunk) * hd.dim);
-    for (int64_t r = 0; r < hd.n; r += chunk) {
-      const int64_t m = std::min(chunk, hd.n - r);
-      if (fread(host.data(), 2, (size_t)m * hd.dim, f) != (size_t)m * hd.dim) return bail(VDB_ERR_IO, "load: short read");
-      hipError_t e = hipMemset2DAsync(h->rows_bf16 + (size_t)r * h->ld, (size_t)h->ld * 2, 0, (size_t)h->ld * 2, (size_t)m, h->stream);
-      if (e == hipSuccess) e = hipMemcpy2DAsync(h->rows_bf16 + (size_t)r * h->ld, (size_t)h->ld * 2, host.data(), (size_t)hd.dim * 2, (size_t)hd.dim * 2, (size_t)m, hipMemcpyHostToDevice, h->stream);
-      if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-      if (e != hipSuccess) return bail(VDB_ERR_DEVICE, hipGetErrorString(e));
-    }
+  std::string why;
+  rc = read_rows(h, f, hd.stored_dtype, hd.n, &why);
+  fclose(f);
+  if (rc) { vdb_destroy(h); return fail(nullptr, rc, why); }
+  *out = h;
+  return VDB_OK;
+}
+
+int vdb_load_sharded(vdb_t** out, const char* dir, int dtype, int keep_f32, const int* device_ids, int n_devices) {
+  if (!out || !dir) return fail(nullptr, VDB_ERR_ARG, "load: NULL argument");
+  FILE* f = nullptr;
+  vdb_file_header hd;
+  int rc = open_store(dir, &f, &hd);
+  if (rc) return rc;
+  if (hd.stored_dtype == VDB_BF16 && (dtype == VDB_F32 || keep_f32)) { fclose(f); return fail(nullptr, VDB_ERR_STATE, "load: file holds bf16 rows only; cannot rebuild fp32 rows"); }
+  vdb_t* p = nullptr;
+  rc = vdb_create_sharded(&p, hd.dim, dtype, keep_f32, device_ids, n_devices);
+  if (rc) { fclose(f); return rc; }
+  std::string why;
+  if ((rc = vdb_reserve(p, hd.n))) why = p->err;
+  for (size_t s = 0; rc == VDB_OK && s < p->shards.size(); ++s) {
+    const int64_t lo = std::min<int64_t>(hd.n, (int64_t)s * p->per);
+    const int64_t hi = s + 1 == p->shards.size() ? hd.n : std::min<int64_t>(hd.n, (int64_t)(s + 1) * p->per);
+    rc = read_rows(p->shards[s], f, hd.stored_dtype, hi - lo, &why);
   }
   fclose(f);
-  h->n = hd.n;
-  *out = h;
+  if (rc) { vdb_destroy(p); return fail(nullptr, rc, why); }
+  p->n = hd.n;
+  *out = p;
   return VDB_OK;
 }
 
 int vdb_last_timing(vdb_t* h, float* scan_ms, float* merge_ms, double* bytes) {
   if (!h) return VDB_ERR_ARG;
+  if (is_sharded(h)) {   // the slowest shard's phases; bytes summed over the shards
+    float a = 0.f, b = 0.f; double by = 0.0;
+    for (vdb_t* c : h->shards) {
+      float x = 0.f, y = 0.f; double z = 0.0;
+      const int rc = vdb_last_timing(c, &x, &y, &z);
+      if (rc) return fail(h, rc, c->err);
+      a = std::max(a, x); b = std::max(b, y); by += z;
+    }
+    if (scan_ms) *scan_ms = a;
+    if (merge_ms) *merge_ms = b;
+    if (bytes) *bytes = by;
+    return VDB_OK;
+  }
   if (!h->timing_valid) return fail(h, VDB_ERR_STATE, "last_timing: no search has run on this handle");
   int rc = set_device(h);
   if (rc) return rc;
@@ -1020,6 +1183,19 @@ int vdb_last_timing(vdb_t* h, float* scan_ms, float* merge_ms, double* bytes) {
 
 int vdb_timing_stats(vdb_t* h, int64_t* n_searches, double* scan_ms_sum, double* merge_ms_sum, int reset) {
   if (!h) return VDB_ERR_ARG;
+  if (is_sharded(h)) {   // the shard with the largest scan total (every shard records the same searches)
+    int64_t n = 0; double a = 0.0, b = 0.0;
+    for (vdb_t* c : h->shards) {
+      int64_t cn = 0; double x = 0.0, y = 0.0;
+      const int rc = vdb_timing_stats(c, &cn, &x, &y, reset);
+      if (rc) return fail(h, rc, c->err);
+      if (x >= a) { a = x; b = y; n = cn; }
+    }
+    if (n_searches) *n_searches = n;
+    if (scan_ms_sum) *scan_ms_sum = a;
+    if (merge_ms_sum) *merge_ms_sum = b;
+    return VDB_OK;
+  }
   int rc = set_device(h);
   if (rc) return rc;
   const int64_t cap = (int64_t)(h->ring.size() / 3);
@@ -1042,11 +1218,16 @@ int vdb_timing_stats(vdb_t* h, int64_t* n_searches, double* scan_ms_sum, double*
 
 int vdb_set_option(vdb_t* h, const char* name, int64_t value) {
   if (!h || !name) return VDB_ERR_ARG;
+  if (is_sharded(h)) {   // every shard gets the same setting
+    for (vdb_t* c : h->shards) { const int rc = vdb_set_option(c, name, value); if (rc) return fail(h, rc, c->err); }
+    return VDB_OK;
+  }
   if (!strcmp(name, "scan_blocks_per_cu")) { if (value < 1 || value > 32) return fail(h, VDB_ERR_ARG, "scan_blocks_per_cu must be in [1,32]"); h->scan_blocks_per_cu = (int)value; return VDB_OK; }
   if (!strcmp(name, "timing_ring")) {
     if (value < 1 || value > 65536) return fail(h, VDB_ERR_ARG, "timing_ring must be in [1,65536]");
     int rc = set_device(h);
     if (rc) return rc;
+    if (h->split[0].pending || h->split[1].pending) return fail(h, VDB_ERR_STATE, "timing_ring: a two-phase scan holds events of the current ring");
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return resize_ring(h, (int)value);
   }
@@ -1055,9 +1236,10 @@ int vdb_set_option(vdb_t* h, const char* name, int64_t value) {
     h->timing_every = (int)value; h->n_calls = 0; return VDB_OK;
   }
   if (!strcmp(name, "scan_nt_loads")) { h->scan_nt_loads = value != 0; return VDB_OK; }
+  if (!strcmp(name, "stream_nt_loads")) { h->stream_nt = value != 0; return VDB_OK; }
   if (!strcmp(name, "mfma_ablate")) { h->mfma_ablate = (int)value; return VDB_OK; }
   if (!strcmp(name, "mfma_variant")) {
-    if (value < 3 || value > 5) return fail(h, VDB_ERR_ARG, "mfma_variant must be 3, 4 or 5");
+    if (value < 4 || value > 6) return fail(h, VDB_ERR_ARG, "mfma_variant must be 4, 5 or 6");
     h->mfma_variant = (int)value; return VDB_OK;
   }
   if (!strcmp(name, "mfma_split_x1000")) {
@@ -1078,7 +1260,17 @@ int vdb_set_option(vdb_t* h, const char* name, int64_t value) {
 int vdb_get_stat(vdb_t* h, const char* name, int64_t* value) {
   if (!h || !name || !value) return VDB_ERR_ARG;
   if (!strcmp(name, "rows")) { *value = h->n; return VDB_OK; }
+  if (!strcmp(name, "n_shards")) { *value = is_sharded(h) ? (int64_t)h->shards.size() : 1; return VDB_OK; }
+  if (is_sharded(h)) {
+    if (!strcmp(name, "rows_per_shard")) { *value = h->per; return VDB_OK; }
+    if (!strcmp(name, "capacity_rows")) { *value = 0; for (vdb_t* c : h->shards) *value += c->cap; return VDB_OK; }
+    if (!strcmp(name, "p2p_direct_shards")) { *value = 0; for (char d : h->shard_direct) *value += d; return VDB_OK; }
+    const int rc = vdb_get_stat(h->shards[0], name, value);   // everything else: shard 0's
+    return rc ? fail(h, rc, h->shards[0]->err) : VDB_OK;
+  }
   if (!strcmp(name, "capacity_rows")) { *value = h->cap; return VDB_OK; }
+  if (!strcmp(name, "last_path")) { *value = h->last_path; return VDB_OK; }
+  if (!strcmp(name, "last_corpus_passes")) { *value = h->last_passes; return VDB_OK; }
   if (!strcmp(name, "mfma_last_overflow")) {
     *value = 0;
     if (!h->w_cand_cnt.p || h->mfma_last_b <= 0) return VDB_OK;
@@ -1117,13 +1309,13 @@ int vdb_get_stat(vdb_t* h, const char* name, int64_t* value) {
     if (rd && (!src || bytes < ((size_t)64 << 20))) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return fail(h, VDB_ERR_ARG, "probe_hbm_read_mbps needs a store of at least 64 MiB to stream"); }
     const int iters = 40000;
     double best = 0.0;
+    // read probe: the scan's own launch shape — 12 KiB contiguous per wave and step, non-temporal, 256 threads,
+    // 2 or 4 blocks per CU (the scan runs 2) — best of 4 timed launches each after a warm-up launch
+    const size_t n16 = bytes / 16 / (12 * 64) * (12 * 64);   // whole 12 KiB tiles
     for (int rep = 0; rep < (rd ? 9 : 4); ++rep) {
       HIP_TRY(h, hipEventRecord(e0, h->stream));
-      // read probe: best over {4, 8} blocks per CU x {4, 8, 12} loads in flight per lane (+ a warm-up launch)
-      const int gm = (rep & 1) ? 8 : 4, u = ((rep + 1) / 2) % 3;
-      if (rd && u == 0) hipLaunchKernelGGL((probe_read_kernel<4>), dim3(h->n_cu * gm), dim3(256), 0, h->stream, (const v4u_t*)src, bytes / 16, (unsigned*)h->w_thr.p);
-      else if (rd && u == 1) hipLaunchKernelGGL((probe_read_kernel<8>), dim3(h->n_cu * gm), dim3(256), 0, h->stream, (const v4u_t*)src, bytes / 16, (unsigned*)h->w_thr.p);
-      else if (rd) hipLaunchKernelGGL((probe_read_kernel<12>), dim3(h->n_cu * gm), dim3(256), 0, h->stream, (const v4u_t*)src, bytes / 16, (unsigned*)h->w_thr.p);
+      const int gm = (rep & 1) ? 2 : 4;
+      if (rd) hipLaunchKernelGGL((probe_read_kernel<12>), dim3(h->n_cu * gm), dim3(256), 0, h->stream, (const v4u_t*)src, n16, (unsigned*)h->w_thr.p);
       else hipLaunchKernelGGL(probe_mfma_kernel, dim3(h->n_cu), dim3(512), 0, h->stream, iters, (float*)h->w_thr.p);
       HIP_TRY(h, hipGetLastError());
       HIP_TRY(h, hipEventRecord(e1, h->stream));
@@ -1131,7 +1323,7 @@ int vdb_get_stat(vdb_t* h, const char* name, int64_t* value) {
       float ms = 0.f;
       HIP_TRY(h, hipEventElapsedTime(&ms, e0, e1));
       if (rep == 0 || ms <= 0.f) continue;   // first launch warms up
-      const double v = rd ? (double)bytes / (ms * 1e-3) / 1e6 : (double)h->n_cu * 8 * iters * 8 * 32768.0 / (ms * 1e-3) / 1e9;
+      const double v = rd ? (double)n16 * 16 / (ms * 1e-3) / 1e6 : (double)h->n_cu * 8 * iters * 8 * 32768.0 / (ms * 1e-3) / 1e9;
       best = std::max(best, v);
     }
     (void)hipEventDestroy(e0);
@@ -1160,6 +1352,7 @@ int vdb_synth_rows_dev(vdb_t* h, float* out_dev, int64_t row0, int64_t n, const 
   if (!h) return VDB_ERR_ARG;
   if (!spec || n < 0 || (n > 0 && !out_dev)) return fail(h, VDB_ERR_ARG, "synth: bad arguments");
   if (n == 0) return VDB_OK;
+  if (is_sharded(h)) return vdb_synth_rows_dev(h->shards[0], out_dev, row0, n, spec, stream);   // shard 0's device
   int rc = set_device(h);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;  // NULL = the default (null) stream, HIP convention
@@ -1173,6 +1366,17 @@ int vdb_add_synth(vdb_t* h, int64_t row0, int64_t n, const vdb_synth_spec* spec)
   if (!h) return VDB_ERR_ARG;
   if (!spec || n < 0) return fail(h, VDB_ERR_ARG, "add_synth: bad arguments");
   if (n == 0) return VDB_OK;
+  if (is_sharded(h)) {   // every shard generates its own rows in its own HBM (all GPUs, one after the other)
+    if (!h->per) return fail(h, VDB_ERR_STATE, "vdb_add_synth: call vdb_reserve(total rows) on a sharded handle first (it fixes the row partition)");
+    for (int64_t r = 0; r < n;) {
+      const ShardSpan sp = shard_span(h, h->n, n - r);
+      vdb_t* c = h->shards[(size_t)sp.s];
+      const int rc = vdb_add_synth(c, row0 + r, sp.count, spec);
+      if (rc) return fail(h, rc, c->err);
+      r += sp.count; h->n += sp.count;
+    }
+    return VDB_OK;
+  }
   int rc = set_device(h);
   if (rc) return rc;
   if ((rc = reserve_for_add(h, n))) return rc;

@@ -8,7 +8,7 @@ for cosine space and answers k-nearest queries — here exactly, on the GPU.
 from __future__ import annotations
 
 import ctypes as C
-from typing import Optional, Tuple
+from typing import Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -33,19 +33,27 @@ class FlatIndex:
     fp32 (``dtype='f32'``) or bf16 (+ optional fp32 copy for the rerank)."""
 
     def __init__(self, dim: int, dtype: str = "f32", keep_f32_for_rerank: bool = True,
-                 device: int = 0, lib=None, _handle=None):
+                 device: int = 0, lib=None, _handle=None, devices: Optional[Sequence[int]] = None):
+        """devices=[d0, d1, ...]: ONE handle row-sharded over those GPUs inside this process
+        (vdb_create_sharded; an id may repeat).  Call reserve(total_rows) before adding rows: it
+        fixes the partition.  Results are bit-identical to a single store of the same rows."""
         if dtype not in _DTYPES:
             raise ValueError(f"dtype must be one of {sorted(_DTYPES)}; got {dtype!r}")
         self._lib = lib if lib is not None else _capi.load_library()
         self.dim = int(dim)
         self.dtype = "bf16" if _DTYPES[dtype] == _capi.VDB_BF16 else "f32"
         self.keep_f32 = bool(keep_f32_for_rerank) or self.dtype == "f32"
-        self.device = int(device)
+        self.devices = [int(d) for d in devices] if devices is not None else None
+        self.device = self.devices[0] if self.devices else int(device)
         if _handle is not None:
             self._h = _handle
         else:
             h = C.c_void_p()
-            rc = self._lib.vdb_create(C.byref(h), self.dim, _DTYPES[dtype], int(self.keep_f32), self.device)
+            if self.devices is not None:
+                ids = (C.c_int * len(self.devices))(*self.devices)
+                rc = self._lib.vdb_create_sharded(C.byref(h), self.dim, _DTYPES[dtype], int(self.keep_f32), ids, len(self.devices))
+            else:
+                rc = self._lib.vdb_create(C.byref(h), self.dim, _DTYPES[dtype], int(self.keep_f32), self.device)
             _capi.check(self._lib, None, rc)
             self._h = h
 
@@ -178,15 +186,19 @@ class FlatIndex:
 
     @classmethod
     def load(cls, directory: str, dtype: str = "f32", keep_f32_for_rerank: bool = True, device: int = 0,
-             lib=None) -> "FlatIndex":
+             lib=None, devices: Optional[Sequence[int]] = None) -> "FlatIndex":
         lib = lib if lib is not None else _capi.load_library()
         h = C.c_void_p()
-        rc = lib.vdb_load(C.byref(h), str(directory).encode(), _DTYPES[dtype], int(bool(keep_f32_for_rerank)), int(device))
+        if devices is not None:
+            ids = (C.c_int * len(devices))(*[int(d) for d in devices])
+            rc = lib.vdb_load_sharded(C.byref(h), str(directory).encode(), _DTYPES[dtype], int(bool(keep_f32_for_rerank)), ids, len(devices))
+        else:
+            rc = lib.vdb_load(C.byref(h), str(directory).encode(), _DTYPES[dtype], int(bool(keep_f32_for_rerank)), int(device))
         _capi.check(lib, None, rc)
         # dim is recorded in the file header (bytes 8..12)
         with open(f"{directory}/vectors.vdb", "rb") as f:
             dim = int(np.frombuffer(f.read(16)[8:12], dtype=np.int32)[0])
-        return cls(dim, dtype, keep_f32_for_rerank, device, lib=lib, _handle=h)
+        return cls(dim, dtype, keep_f32_for_rerank, device, lib=lib, _handle=h, devices=devices)
 
     # -- measurement -------------------------------------------------------
     def last_timing(self) -> dict:

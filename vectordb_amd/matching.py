@@ -99,10 +99,12 @@ def find_best_usda_match(product_embedding: np.ndarray, usda_embeddings: Dict[st
 
 
 def best_usda_matches_batched(product_embeddings, usda_embeddings: Dict[str, np.ndarray], device: int = 0,
-                              lib=None) -> Tuple[List[str], np.ndarray]:
+                              lib=None) -> Tuple[List[Optional[str]], np.ndarray]:
     """All products at once on the GPU: the USDA vectors form a tiny exact store and
     every product is a k=1 query.  Ties resolve to the lowest row = first in dict
-    order, as the strict '>' loop does."""
+    order, as the strict '>' loop does.  A product the engine returns nothing for
+    (a non-finite embedding: idx -1, distance +inf) maps to (None, -1.0), which is
+    what the reference's loop reports for it (every comparison with NaN is false)."""
     codes = list(usda_embeddings)
     mat = np.stack([np.asarray(usda_embeddings[c], dtype=np.float32).reshape(-1) for c in codes])
     idx = FlatIndex(mat.shape[1], "f32", True, device, lib=lib)
@@ -111,4 +113,6 @@ def best_usda_matches_batched(product_embeddings, usda_embeddings: Dict[str, np.
         rows, dist = idx.search(np.asarray(product_embeddings, dtype=np.float32), 1)
     finally:
         idx.close()
-    return [codes[r] for r in rows[:, 0]], 1.0 - dist[:, 0].astype(np.float64)
+    hit = rows[:, 0] >= 0
+    sims = np.where(hit, 1.0 - dist[:, 0].astype(np.float64), -1.0)
+    return [codes[r] if ok else None for r, ok in zip(rows[:, 0], hit)], sims
