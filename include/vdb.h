@@ -139,6 +139,17 @@ int vdb_search(vdb_t* h, const float* queries_host, int b, int k, int rerank_kpr
 int vdb_search_dev(vdb_t* h, const float* queries_dev, int b, int k, int rerank_kprime,
                    int64_t* out_idx_dev, float* out_dist_dev, void* stream);
 
+/* vdb_search_dev for callers that cannot call hipMalloc: code under HIP graph capture, tight serving loops, harnesses
+ * that forbid allocation.  NO COUNTERPART IN THE REFERENCE.  Same inputs, outputs and results as vdb_search_dev, but
+ * the search always runs on the GEMV scan and its workspaces (normalised queries, partial top-k' lists) come out of a
+ * fixed array in device memory that the library holds per GPU (2.3 MiB, "scratch_bytes" in vdb_get_stat) instead of
+ * the handle's grown-on-demand buffers: the call makes no hipMalloc/hipFree and creates no event.  Limits (beyond
+ * them: VDB_ERR_ARG, nothing is launched): b <= 8 queries, k (k' when reranking) <= 64, dim <= 4096.  All calls on
+ * one GPU — from any handle — share that GPU's array: calls that overlap in time on one GPU race; issue them on one
+ * stream, or order them yourself.  No timing events are recorded (vdb_last_timing keeps the previous search's). */
+int vdb_search_dev_noalloc(vdb_t* h, const float* queries_dev, int b, int k, int rerank_kprime,
+                           int64_t* out_idx_dev, float* out_dist_dev, void* stream);
+
 /* vdb_search_dev in two phases, for callers that pipeline batches (the multi-GPU exchange of SURVEY 8e):
  * phase 1 normalises the queries and scans the corpus (the HBM-bound part), phase 2 merges the partial lists,
  * reranks and ranks.  The phases may run on different streams (the caller orders phase 2 after phase 1 with an
@@ -229,7 +240,7 @@ int vdb_set_option(vdb_t* h, const char* name, int64_t value);
 
 /* Read-only counters/diagnostics (synchronises the device): "mfma_last_overflow" (1 when the
  * last batched search overflowed its candidate buffers and ran the exact list kernel),
- * "rows", "capacity_rows", "n_shards", "rows_per_shard" and "p2p_direct_shards" (sharded handles),
+ * "rows", "capacity_rows", "n_shards", "rows_per_shard" and "p2p_direct_shards" (sharded handles), "scratch_bytes",
  * "last_path" (kernel family of the last search: 0 = GEMV scan, 4 / 5 = tiled MFMA kernels, 6 = streaming MFMA kernel),
  * "last_corpus_passes" (corpus passes of the last search: the roofline's algorithmic bytes = passes x rows x row bytes),
  * "mfma_last_hits", "mfma_last_skipped_tiles" (tiles the final pass of the last

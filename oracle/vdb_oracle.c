@@ -348,6 +348,13 @@ int vdb_search_dev(vdb_t* h, const float* q, int b, int k, int kp, int64_t* oi, 
   (void)stream;
   return vdb_search(h, q, b, k, kp, oi, od);
 }
+int vdb_search_dev_noalloc(vdb_t* h, const float* q, int b, int k, int kp, int64_t* oi, float* od, void* stream) {
+  if (!h) return VDB_ERR_ARG;
+  if (b > 8) return fail(h, VDB_ERR_ARG, "search_dev_noalloc: at most 8 queries per call (the fixed scratch array holds no more)");
+  if ((kp ? kp : k) > 64) return fail(h, VDB_ERR_ARG, "search_dev_noalloc: k (k' when reranking) must be <= 64");
+  if (h->dim > 4096) return fail(h, VDB_ERR_ARG, "search_dev_noalloc: dim must be <= 4096");
+  return vdb_search_dev(h, q, b, k, kp, oi, od, stream);
+}
 /* two-phase form: the CPU twin keeps the queries in phase 1 and searches in phase 2 */
 int vdb_search_scan_dev(vdb_t* h, const float* q, int b, int k, int kp, int slot, void* stream) {
   (void)stream;
@@ -529,7 +536,7 @@ int vdb_get_stat(vdb_t* h, const char* name, int64_t* value) {
   if (!strcmp(name, "rows")) { *value = h->n; return VDB_OK; }
   if (!strcmp(name, "capacity_rows")) { *value = h->cap; return VDB_OK; }
   if (!strcmp(name, "n_shards")) { *value = h->n_shards ? h->n_shards : 1; return VDB_OK; }
-  if (!strcmp(name, "last_path") || !strcmp(name, "p2p_direct_shards")) { *value = 0; return VDB_OK; }
+  if (!strcmp(name, "last_path") || !strcmp(name, "scratch_bytes") || !strcmp(name, "p2p_direct_shards")) { *value = 0; return VDB_OK; }
   if (!strcmp(name, "last_corpus_passes")) { *value = 1; return VDB_OK; }
   if (!strcmp(name, "mfma_last_overflow") || !strcmp(name, "mfma_last_hits") || !strcmp(name, "mfma_last_skipped_tiles")) { *value = 0; return VDB_OK; }
   return fail(h, VDB_ERR_ARG, "get_stat: unknown stat");

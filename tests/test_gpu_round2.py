@@ -66,6 +66,7 @@ def test_stream_kernel_multi_pass_and_selfjoin(hip_lib, oracle_mod):
     queries = oracle_mod.synth_rows(0, 40, dim, qspec)
     ix = FlatIndex(dim, "bf16", True)
     ix.set_option("mfma_cost_model", 0)
+    ix.set_option("mfma_append_cap", 4096)      # smaller candidate buffers -> the protocol takes two append passes at this size
     ix.add_synth(0, n, spec)
     idx, dist = ix.search(queries, 10, 40)
     assert ix.get_stat("last_path") == 6 and ix.get_stat("mfma_last_overflow") == 0
@@ -102,11 +103,15 @@ def test_stream_kernel_overflow_fallback_and_bad_thresholds(hip_lib, oracle_mod,
     ix.set_option("mfma_cost_model", 0)
     ix.add_synth(0, n, spec)
     base_i, base_d = ix.search(queries[:24], 10, 40)
-    ix.set_option("mfma_append_cap", 256)
+    ix.set_option("mfma_append_cap", 256)       # the smallest buffers: more append passes, possibly a real overflow
     i2, d2 = ix.search(queries[:24], 10, 40)
-    assert ix.get_stat("mfma_last_overflow") == 1
     assert np.array_equal(i2, base_i) and np.array_equal(d2, base_d)
     ix.set_option("mfma_append_cap", 16384)
+    ix.set_option("mfma_force_fallback", 1)     # the overflow route itself
+    i3, d3 = ix.search(queries[:24], 10, 40)
+    assert ix.get_stat("mfma_last_overflow") == 1
+    assert np.array_equal(i3, base_i) and np.array_equal(d3, base_d)
+    ix.set_option("mfma_force_fallback", 0)
     neg = -np.abs(queries[:10])            # rows are centroid + noise around 0: mirror the query so that most cosines go negative
     idx, dist = ix.search(neg, 10, 40)
     r_idx, r_dist, r_sc = oracle_mod.exact_topk(rows, neg, 10)
@@ -164,7 +169,8 @@ def test_sharded_handle_equals_single_store(hip_lib, oracle_mod, corpus33k, g, d
     i_g, d_g = sh.search(queries[:9], 10, kp)
     check_topk(i_g, d_g, r_idx, r_dist, r_sc, rows, qn[:9], what=f"sharded g={g} {dtype}")
     # fetch routes global indices to their shards
-    pick = np.array([0, 1, sh.get_stat("rows_per_shard") - 1, sh.get_stat("rows_per_shard") % n, n - 1, 12345], np.int64)
+    per = sh.get_stat("rows_per_shard")
+    pick = np.array([0, 1, min(per, n) - 1, per % n, n - 1, 12345], np.int64)
     assert np.array_equal(sh.fetch(pick), single.fetch(pick))
     t = sh.last_timing()
     assert t["scan_ms"] > 0 and t["bytes_streamed"] > 0

@@ -21,7 +21,7 @@ VDB_MAX_K = 1024
 
 #: every symbol include/vdb.h declares (tests check the built library exports all of them)
 SYMBOLS = (
-    "vdb_create", "vdb_create_sharded", "vdb_load_sharded", "vdb_destroy", "vdb_last_error", "vdb_reserve", "vdb_set_row_offset",
+    "vdb_create", "vdb_create_sharded", "vdb_load_sharded", "vdb_search_dev_noalloc", "vdb_destroy", "vdb_last_error", "vdb_reserve", "vdb_set_row_offset",
     "vdb_add", "vdb_add_dev", "vdb_count", "vdb_search", "vdb_search_dev", "vdb_search_masked", "vdb_search_masked_dev",
     "vdb_search_scan_dev", "vdb_search_finish_dev",
     "vdb_merge_topk_dev",
@@ -54,6 +54,7 @@ def _declare(lib: C.CDLL) -> C.CDLL:
     lib.vdb_create.argtypes = [C.POINTER(vp), i32, i32, i32, i32]
     lib.vdb_create_sharded.argtypes = [C.POINTER(vp), i32, i32, i32, C.POINTER(i32), i32]
     lib.vdb_load_sharded.argtypes = [C.POINTER(vp), C.c_char_p, i32, i32, C.POINTER(i32), i32]
+    lib.vdb_search_dev_noalloc.argtypes = [vp, pf, i32, i32, i32, pi64, pf, vp]
     lib.vdb_destroy.argtypes = [vp]
     lib.vdb_destroy.restype = None
     lib.vdb_last_error.argtypes = [vp]

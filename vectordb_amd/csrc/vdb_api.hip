@@ -32,6 +32,26 @@ struct DevBuf {
   size_t bytes = 0;
 };
 
+// ---- scratch of the entry point that allocates nothing (vdb_search_dev_noalloc) ----------------------------
+// Device memory beyond the inputs and outputs of a GEMV-path search: the normalised queries and the two
+// generations of partial top-k' lists.  A file-scope array, so that the entry point never calls hipMalloc; every
+// GPU the library runs on holds one copy (2.3 MiB) until the process ends.  In host code the array's NAME is
+// only a stand-in: the device address is taken once per device with hipGetSymbolAddress (vdb_create, with that
+// device current) and only that pointer is ever handed to kernels.
+constexpr int kNaMaxB = 8;          // queries per call
+constexpr int kNaMaxKK = 64;        // k (or k' when reranking)
+constexpr int kNaMaxGrid = 512;     // scan blocks = partial lists per query
+constexpr int kNaMaxLd = 4096;      // padded row length
+constexpr size_t kNaQBytes = (size_t)kNaMaxB * kNaMaxLd * 4;                               // 128 KiB
+constexpr size_t kNaPartElems = (size_t)kNaMaxB * kNaMaxGrid * kNaMaxKK;                  // 1 MiB per array
+constexpr size_t kNaPart2Elems = (size_t)kNaMaxB * ((kNaMaxGrid + 31) / 32) * kNaMaxKK;   // after one 32-way fold
+constexpr size_t kNaScratchBytes = kNaQBytes + 8 * kNaPartElems + 8 * kNaPart2Elems;
+static __device__ __align__(256) unsigned char scratch[kNaScratchBytes];
+
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mu;
+void* g_scratch_ptr[kMaxDevices] = {};   // per device: the address of ITS copy of `scratch`
+
 }  // namespace
 
 struct vdb {
@@ -77,6 +97,7 @@ struct vdb {
   int mfma_last_b = 0;           // batch size of the last MFMA search (locates its overflow flag)
   int mfma_last_skipped = 0;     // tiles the last MFMA search's final pass left out (the sample pass's)
   int mfma_force_fallback = 0;   // test hook: route through the exact list kernel
+  void* na_scratch = nullptr;    // this device's copy of `scratch` (hipGetSymbolAddress at create)
   // ---- sharded handle (vdb_create_sharded): a router over per-device shards; none of the fields above but
   // dim/ld/dtype/keep_f32/device(= shard 0's)/stream/pin/w_stage/w_out_i/w_gather are used on it
   std::vector<vdb*> shards;
@@ -193,7 +214,7 @@ void launch_merge(int e, const float* is, const int* ii, int n_cand, int cpb, in
 
 // Where a GEMV-path search keeps its partial lists: two generations [q][part][kk] of (score, row).  The handle owns
 // two such sets (slot 1 lets phase 2 of one batch run on another stream while phase 1 of the next fills slot 0);
-// callers may bring their own.
+// the entry point that allocates nothing brings a third, carved out of the device's `scratch` array.
 struct WsPtrs { float* ps; int* pi; float* p2s; int* p2i; };
 struct WsSet { DevBuf *q, *ps, *pi, *p2s, *p2i; };
 WsSet ws_of(vdb_t* h, int slot) {
@@ -509,6 +530,21 @@ int vdb_create(vdb_t** out, int dim, int dtype, int keep_f32, int device_id) {
   }
   h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (resize_ring(h, 1) != VDB_OK) { vdb_destroy(h); return fail(nullptr, VDB_ERR_DEVICE, "vdb_create: event creation failed"); }
+  // this device's copy of the no-allocation entry point's scratch array: its address is taken ONCE per device,
+  // with the device current (set above); kernels only ever see this pointer, never the array's name
+  if (device_id < kMaxDevices) {
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (!g_scratch_ptr[device_id]) {
+      void* ptr = nullptr;
+      const hipError_t se = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+      if (se != hipSuccess || !ptr) {
+        vdb_destroy(h);
+        return fail(nullptr, VDB_ERR_DEVICE, std::string("vdb_create: hipGetSymbolAddress(scratch): ") + hipGetErrorString(se));
+      }
+      g_scratch_ptr[device_id] = ptr;
+    }
+    h->na_scratch = g_scratch_ptr[device_id];
+  }
   *out = h;
   return VDB_OK;
 }
@@ -729,6 +765,46 @@ int vdb_search_dev(vdb_t* h, const float* queries_dev, int b, int k, int kp, int
   float* qn = nullptr;
   if ((rc = prep_queries(h, queries_dev, b, st, &qn))) return rc;
   return search_core(h, qn, b, k, kp, -1, out_idx_dev, out_dist_dev, st);
+}
+
+// vdb_search_dev for callers that cannot allocate (HIP graph capture, tight serving loops): the GEMV scan with
+// its workspaces carved out of this device's `scratch` array.  No hipMalloc / hipFree / event creation here.
+int vdb_search_dev_noalloc(vdb_t* h, const float* queries_dev, int b, int k, int kp, int64_t* out_idx_dev,
+                           float* out_dist_dev, void* stream) {
+  if (!h) return VDB_ERR_ARG;
+  NOT_ON_SHARDED(h, "vdb_search_dev_noalloc");
+  int rc = check_search_args(h, queries_dev, b, k, kp, out_idx_dev, out_dist_dev);
+  if (rc) return rc;
+  if (b == 0) return VDB_OK;
+  const int kk = kp ? kp : k;
+  if (b > kNaMaxB) return fail(h, VDB_ERR_ARG, "search_dev_noalloc: at most 8 queries per call (the fixed scratch array holds no more)");
+  if (kk > kNaMaxKK) return fail(h, VDB_ERR_ARG, "search_dev_noalloc: k (k' when reranking) must be <= 64");
+  if (h->ld > kNaMaxLd) return fail(h, VDB_ERR_ARG, "search_dev_noalloc: dim must be <= 4096");
+  if (!h->na_scratch) return fail(h, VDB_ERR_STATE, "search_dev_noalloc: no scratch array on this device");
+  if (h->split[0].pending || h->split[1].pending) return fail(h, VDB_ERR_STATE, "search_dev_noalloc: a two-phase scan is pending on this handle");
+  if ((rc = set_device(h))) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (h->n == 0) {
+    hipLaunchKernelGGL(fill_empty_kernel, dim3((b * k + 255) / 256), dim3(256), 0, st, (long long*)out_idx_dev, out_dist_dev, (long long)b * k);
+    HIP_TRY(h, hipGetLastError());
+    return VDB_OK;
+  }
+  const int grid = std::min(gemv_grid(h), kNaMaxGrid);
+  // carve the device's array (its address, taken at vdb_create — never the array's name): queries | lists | folded lists
+  unsigned char* base = (unsigned char*)h->na_scratch;
+  float* qn = (float*)base;
+  WsPtrs P;
+  P.ps = (float*)(base + kNaQBytes);
+  P.pi = (int*)(base + kNaQBytes + 4 * kNaPartElems);
+  P.p2s = (float*)(base + kNaQBytes + 8 * kNaPartElems);
+  P.p2i = (int*)(base + kNaQBytes + 8 * kNaPartElems + 4 * kNaPart2Elems);
+  const int blocks = std::max(1, std::min((b + 3) / 4, h->n_cu * 8));
+  hipLaunchKernelGGL(normalize_rows_kernel, dim3(blocks), dim3(256), 0, st, queries_dev, h->dim, (long long)b, h->dim, h->ld, qn, (uint16_t*)nullptr);
+  HIP_TRY(h, hipGetLastError());
+  h->ev_on = false;               // no timing events on this path
+  h->last_bytes = 0.0; h->last_path = 0; h->last_passes = 0;
+  if ((rc = gemv_scan_chunk(h, P, qn, b, kk, -1, nullptr, grid, st))) return rc;
+  return finish_search(h, P, b, grid, kk, k, kp, qn, out_idx_dev, out_dist_dev, st);
 }
 
 int vdb_search_scan_dev(vdb_t* h, const float* queries_dev, int b, int k, int kp, int slot, void* stream) {
@@ -1261,6 +1337,7 @@ int vdb_get_stat(vdb_t* h, const char* name, int64_t* value) {
   if (!h || !name || !value) return VDB_ERR_ARG;
   if (!strcmp(name, "rows")) { *value = h->n; return VDB_OK; }
   if (!strcmp(name, "n_shards")) { *value = is_sharded(h) ? (int64_t)h->shards.size() : 1; return VDB_OK; }
+  if (!strcmp(name, "scratch_bytes")) { *value = (int64_t)kNaScratchBytes; return VDB_OK; }
   if (is_sharded(h)) {
     if (!strcmp(name, "rows_per_shard")) { *value = h->per; return VDB_OK; }
     if (!strcmp(name, "capacity_rows")) { *value = 0; for (vdb_t* c : h->shards) *value += c->cap; return VDB_OK; }

@@ -156,6 +156,13 @@ class FlatIndex:
         self._chk(self._lib.vdb_search_dev(self._h, int(q_ptr), int(b), int(k), int(rerank_kprime),
                                            int(out_idx_ptr), int(out_dist_ptr), stream or None))
 
+    def search_device_noalloc(self, q_ptr: int, b: int, k: int, rerank_kprime: int, out_idx_ptr: int,
+                              out_dist_ptr: int, stream: int = 0) -> None:
+        """search_device for callers that cannot allocate (HIP graph capture, serving loops): at most 8 queries,
+        k (k') <= 64; workspaces come from the library's fixed per-GPU scratch array."""
+        self._chk(self._lib.vdb_search_dev_noalloc(self._h, int(q_ptr), int(b), int(k), int(rerank_kprime),
+                                                   int(out_idx_ptr), int(out_dist_ptr), stream or None))
+
     def merge_topk_device(self, cand_dist_ptr: int, cand_idx_ptr: int, g: int, b: int, k: int,
                           out_idx_ptr: int, out_dist_ptr: int, stream: int = 0,
                           dist_shard_stride: int = 0, idx_shard_stride: int = 0) -> None:
