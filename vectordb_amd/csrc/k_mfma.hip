@@ -20,7 +20,7 @@ MfGrid mf_grid(int n_cu, int n_qt, long long pass_tiles, int max_splits) {
   return g;
 }
 
-static_assert(kMfDenseLdC == kMf3DenseLd && kMfRowBytesC == kMfRowBytes, "launch.h mirrors the kernels' constants");
+static_assert(kMfDenseLdC == kMf3DenseLd && kMfRowBytesC == kMfRowBytes && kMfCntStrideC == kMfCntStride, "launch.h mirrors the kernels' constants");
 
 #define MF_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return e_; } while (0)
 
@@ -70,7 +70,7 @@ hipError_t mfma_search_launch(const MfSearchArgs& a, int* skipped_tiles) {
   const unsigned char* rows = a.rows_bf16;
   const unsigned char* qb16 = a.qb16;
   float* cand_s = a.cand_s; int* cand_i = a.cand_i; int* cand_cnt = a.cand_cnt;
-  int* ovf = cand_cnt + b;
+  int* ovf = cand_cnt + (size_t)b * kMfCntStride;
   float* thr = a.thr; float* dense = a.dense;
   hipStream_t st = a.st;
   if (skipped_tiles) *skipped_tiles = 0;
@@ -85,7 +85,7 @@ hipError_t mfma_search_launch(const MfSearchArgs& a, int* skipped_tiles) {
   auto launch_pass = [&](int mode, long long pass_tiles, int stride, int skip_n) -> hipError_t {
     if (variant == 6) {
       stream_launch_pass(mode, rows, n_rows, qb16, b, (int)pass_tiles, stride, skip_n, self0, mode ? (const float*)thr : nullptr, dense,
-                         cand_cnt, cand_s, cand_i, cap, a.n_cu, a.stream_nt, st);
+                         cand_cnt, cand_s, cand_i, cap, a.n_cu, a.stream_nt, a.stream_blocks_per_cu, st);
       return hipGetLastError();
     }
     const MfGrid g = mf_grid(a.n_cu, n_qt, pass_tiles, 1 << 30);
@@ -142,7 +142,7 @@ hipError_t mfma_search_launch(const MfSearchArgs& a, int* skipped_tiles) {
     int skip_n = 0;
     long long pass_tiles = t_next;
     if (last && seeded) { stride = seed_stride; skip_n = seed_n; pass_tiles = n_tiles - skip_n; if (skipped_tiles) *skipped_tiles = skip_n; }
-    MF_TRY(hipMemsetAsync(cand_cnt, 0, (size_t)b * 4, st));
+    MF_TRY(hipMemsetAsync(cand_cnt, 0, (size_t)b * kMfCntStride * 4, st));
     if (pass_tiles > 0) MF_TRY(launch_pass(1, pass_tiles, stride, skip_n));
     // the sample pass of a two-pass search keeps its sorted list when the last pass can leave its tiles out
     const bool keep = !last && n_pass == 2 && stride >= 2 && a.skip_sample;

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(1024) void select_kth_kernel(const float* __restric
   const int lane = lane_id();
   int n = cap_or_n;
   if (cand_cnt) {
-    const int c = cand_cnt[q];
+    const int c = cand_cnt[q * kMfCntStride];
     if (c > cap_or_n) { if (threadIdx.x == 0) *overflow = 1; }
     else n = c;
   }

@@ -227,7 +227,7 @@ __global__ __launch_bounds__(kWsThreads) void scan_mfma_ws_kernel(
           const int row = (int)tile_row0 + rloc;
           if (needs_mask) pass = pass && (row < n_rows) && (qg < b) && !(self0 >= 0 && row == self0 + qg);
           if (pass) {
-            const int pos = atomicAdd(&cand_cnt[qg], 1);
+            const int pos = atomicAdd(&cand_cnt[qg * kMfCntStride], 1);
             if (pos < cap) { cand_s[(size_t)qg * cap + pos] = v; cand_i[(size_t)qg * cap + pos] = row; }
           }
         }

@@ -203,7 +203,7 @@ __global__ __launch_bounds__(kM5Threads) void scan_mfma_wide_kernel(
   auto flush_pending = [&]() {
     int pos[kPend];
 #pragma unroll
-    for (int s = 0; s < kPend; ++s) pos[s] = s < pend_n ? atomicAdd(&cand_cnt[pend_q[s]], 1) : cap;   // all in flight, one wait
+    for (int s = 0; s < kPend; ++s) pos[s] = s < pend_n ? atomicAdd(&cand_cnt[pend_q[s] * kMfCntStride], 1) : cap;   // all in flight, one wait
 #pragma unroll
     for (int s = 0; s < kPend; ++s)
       if (pos[s] < cap) { cand_s[(size_t)pend_q[s] * cap + pos[s]] = pend_v[s]; cand_i[(size_t)pend_q[s] * cap + pos[s]] = pend_row[s]; }

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(kStThreads, (NQ <= 2 ? 4 : 2)) void scan_stream_ker
           for (int reg = 0; reg < 4; ++reg) {
             const int row = row0 + 4 * c + reg;
             const bool pass = (acc[nq][reg] >= thr[nq]) && (row < n_rows) && (qg < b) && !(self0 >= 0 && row == self0 + qg);
-            pos[nq][reg] = pass ? atomicAdd(&cand_cnt[qg], 1) : cap;   // all in flight, one wait
+            pos[nq][reg] = pass ? atomicAdd(&cand_cnt[qg * kMfCntStride], 1) : cap;   // all in flight, one wait
           }
         }
 #pragma unroll
@@ -196,10 +196,10 @@ inline hipError_t stream_prepare_device() {
 // one pass over n_pass_tiles protocol tiles (pass_tile(i, stride, skip_n)); mode 0 = dense sample, 1 = append
 inline void stream_launch_pass(int mode, const unsigned char* rows, int n_rows, const unsigned char* qb16, int b, int n_pass_tiles,
                                int tile_stride, int skip_n, int self0, const float* thr, float* dense, int* cand_cnt,
-                               float* cand_s, int* cand_i, int cap, int n_cu, int nt, hipStream_t st) {
+                               float* cand_s, int* cand_i, int cap, int n_cu, int nt, int blocks_per_cu, hipStream_t st) {
   const int nq = st_blocks(b);
   const long long units = (long long)n_pass_tiles * kStSub;
-  const int per_cu = nq <= 2 ? 2 : 1;
+  const int per_cu = blocks_per_cu > 0 ? blocks_per_cu : (nq <= 2 ? 2 : 1);
   const int grid = (int)std::max<long long>(1, std::min<long long>((long long)n_cu * per_cu, (units + kStWaves - 1) / kStWaves));
 #define ST_LAUNCH(MODE, NQ, NT)                                                                                                   \
   hipLaunchKernelGGL((scan_stream_kernel<MODE, NQ, NT>), dim3(grid), dim3(kStThreads), st_smem_bytes(NQ), st, rows, n_rows, qb16, b, \

@@ -80,6 +80,7 @@ struct vdb {
   int mfma_cost_model = 1;       // 0: every supported batch >= batch_mfma_min_b takes the MFMA path (tests)
   int mfma_ablate = 0;   // diagnostic: skip parts of the MFMA kernel (wrong results, timing only)
   int stream_nt = 0;     // the streaming kernel's corpus loads: 0 = plain, 1 = non-temporal
+  int stream_blocks_per_cu = 0;   // 0 = the kernel's own choice
   // workspaces (grown on demand)
   DevBuf w_q, w_part_s, w_part_i, w_part2_s, w_part2_i, w_stage, w_out_i, w_out_d, w_idx, w_mfma;
   DevBuf w_q1, w_part_s1, w_part_i1, w_part2_s1, w_part2_i1;   // second set: slot 1 of the two-phase search
@@ -285,7 +286,7 @@ int mfma_search(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
   if ((rc = ensure(h, h->w_mfma, (size_t)pl.b_pad * kMfRowBytesC))) return rc;
   if ((rc = ensure(h, h->w_cand_s, (size_t)b * cap * 4))) return rc;
   if ((rc = ensure(h, h->w_cand_i, (size_t)b * cap * 4))) return rc;
-  if ((rc = ensure(h, h->w_cand_cnt, (size_t)(b + 16) * 4))) return rc;   // [b] counters + overflow flag at [b]
+  if ((rc = ensure(h, h->w_cand_cnt, ((size_t)b * kMfCntStrideC + 16) * 4))) return rc;   // [b] counters, one cache line each, + the overflow flag
   if ((rc = ensure(h, h->w_thr, (size_t)b * 4))) return rc;
   if ((rc = ensure(h, h->w_dense, (size_t)b * kMfDenseLdC * 4))) return rc;
   if ((rc = ensure(h, h->w_list_s, (size_t)b * kk * 4))) return rc;
@@ -303,7 +304,7 @@ int mfma_search(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
   a.rows_bf16 = (const unsigned char*)h->rows_bf16; a.n_rows = n_rows; a.qn = qn; a.b = b; a.kk = kk;
   a.self0 = self_row0 >= 0 ? (int)self_row0 : -1;
   a.n_cu = h->n_cu; a.variant = h->mfma_variant; a.cap = cap; a.split_x1000 = h->mfma_split_x1000;
-  a.skip_sample = h->mfma_skip_sample; a.force_fallback = h->mfma_force_fallback; a.ablate = h->mfma_ablate; a.stream_nt = h->stream_nt;
+  a.skip_sample = h->mfma_skip_sample; a.force_fallback = h->mfma_force_fallback; a.ablate = h->mfma_ablate; a.stream_nt = h->stream_nt; a.stream_blocks_per_cu = h->stream_blocks_per_cu;
   a.qb16 = (unsigned char*)h->w_mfma.p;
   a.cand_s = (float*)h->w_cand_s.p; a.cand_i = (int*)h->w_cand_i.p; a.cand_cnt = (int*)h->w_cand_cnt.p;
   a.thr = (float*)h->w_thr.p; a.dense = (float*)h->w_dense.p;
@@ -317,7 +318,7 @@ int mfma_search(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
   HIP_TRY(h, mfma_search_launch(a, &h->mfma_last_skipped));
   h->last_bytes = (double)n_rows * kMfRowBytesC;
   if (h->ev_on && last_chunk) HIP_TRY(h, hipEventRecord(h->ev[1], st));
-  const int* ovf = a.cand_cnt + b;
+  const int* ovf = a.cand_cnt + (size_t)b * kMfCntStrideC;
   if (kp)
     hipLaunchKernelGGL((final_sorted_kernel<true>), dim3(b), dim3(1024), 0, st, (const float*)a.list_s, (const int*)a.list_i, 1, kk, k,
                        (long long)h->row_offset, (const float*)h->rows_f32, h->ld, qn, (long long*)out_idx, out_dist,
@@ -330,20 +331,23 @@ int mfma_search(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
   return VDB_OK;
 }
 
-// Which path serves a bf16 768-d batch faster?  Coefficients measured on MI355X (10M and 1M rows):
-// a GEMV pass costs a launch (~12 us) plus the corpus at ~6.7 TB/s, times 1.0 / 1.18 / 1.64 for 1 / 2 / 4
-// queries per pass (b = 3 runs as 2 + 1).  The batched path costs ~100 us of launches (dense sample, selects,
-// append passes) plus, per row: the streaming kernel (<= 64 queries) the corpus at ~6.3 TB/s; the tiled kernels
-// 0.29 ns per 128-query tile or 0.36 (+0.05) ns per 256-query tile.
+// Which path serves a bf16 768-d batch faster?  Coefficients measured on MI355X (10M and 1M rows, round 2):
+// a GEMV pass costs a launch (~12 us) plus the corpus at ~6.7 TB/s, times 1.0 / 1.10 / 1.64 for 1 / 2 / 4
+// queries per pass (b = 3 runs as 2 + 1).  The batched path costs ~110 us of launches (dense sample, selects,
+// append passes) plus, per row: the streaming kernel (<= 64 queries) the corpus at ~6.0 TB/s (its 64-byte row
+// pieces are half cache lines: the memory path takes ~13 % fewer bytes per second than from whole lines); the
+// tiled kernels 0.25 ns per 128-query tile or 0.36 (+0.05) ns per 256-query tile.
+// Measured at 10M rows: b = 2 GEMV 2.42-2.51 ms vs streaming 2.67; b = 4 3.70 vs 2.66; b = 64 58.6 vs 2.70;
+// b = 128 tiled 3.29.
 bool mfma_is_faster(int b, int n_rows, int variant_opt) {
   const double pass = 12e-6 + (double)n_rows * kMfRowBytesC / 6.7e12;
   const int r = b & 3;
-  const double gemv = pass * (1.64 * (b >> 2) + (r == 3 ? 2.18 : r == 2 ? 1.18 : r == 1 ? 1.0 : 0.0));
+  const double gemv = pass * (1.64 * (b >> 2) + (r == 3 ? 2.10 : r == 2 ? 1.10 : r == 1 ? 1.0 : 0.0));
   const MfPlan pl = mfma_plan(b, n_rows, 256, variant_opt);
   double mfma;
-  if (pl.variant == 6) mfma = 110e-6 + (double)n_rows * kMfRowBytesC / (b <= 32 ? 6.3e12 : 6.0e12);
+  if (pl.variant == 6) mfma = 110e-6 + (double)n_rows * kMfRowBytesC / 6.0e12;
   else if (pl.variant == 5) mfma = 100e-6 + (double)n_rows * (0.36e-9 * pl.n_qt + 0.05e-9);
-  else mfma = 100e-6 + (double)n_rows * 0.29e-9 * pl.n_qt;
+  else mfma = 100e-6 + (double)n_rows * 0.25e-9 * pl.n_qt;
   return mfma < gemv;
 }
 
@@ -1313,6 +1317,7 @@ int vdb_set_option(vdb_t* h, const char* name, int64_t value) {
   }
   if (!strcmp(name, "scan_nt_loads")) { h->scan_nt_loads = value != 0; return VDB_OK; }
   if (!strcmp(name, "stream_nt_loads")) { h->stream_nt = value != 0; return VDB_OK; }
+  if (!strcmp(name, "stream_blocks_per_cu")) { if (value < 0 || value > 8) return fail(h, VDB_ERR_ARG, "stream_blocks_per_cu must be in [0,8]"); h->stream_blocks_per_cu = (int)value; return VDB_OK; }
   if (!strcmp(name, "mfma_ablate")) { h->mfma_ablate = (int)value; return VDB_OK; }
   if (!strcmp(name, "mfma_variant")) {
     if (value < 4 || value > 6) return fail(h, VDB_ERR_ARG, "mfma_variant must be 4, 5 or 6");
@@ -1355,7 +1360,7 @@ int vdb_get_stat(vdb_t* h, const char* name, int64_t* value) {
     if (rc) return rc;
     int flag = 0;
     HIP_TRY(h, hipDeviceSynchronize());
-    HIP_TRY(h, hipMemcpy(&flag, (int*)h->w_cand_cnt.p + h->mfma_last_b, 4, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(&flag, (int*)h->w_cand_cnt.p + (size_t)h->mfma_last_b * kMfCntStrideC, 4, hipMemcpyDeviceToHost));
     *value = flag != 0;
     return VDB_OK;
   }
@@ -1414,11 +1419,11 @@ int vdb_get_stat(vdb_t* h, const char* name, int64_t* value) {
     if (!h->w_cand_cnt.p || h->mfma_last_b <= 0) return VDB_OK;
     int rc = set_device(h);
     if (rc) return rc;
-    std::vector<int> cnt((size_t)h->mfma_last_b);
+    std::vector<int> cnt((size_t)h->mfma_last_b * kMfCntStrideC);
     HIP_TRY(h, hipDeviceSynchronize());
     HIP_TRY(h, hipMemcpy(cnt.data(), h->w_cand_cnt.p, cnt.size() * 4, hipMemcpyDeviceToHost));
     int64_t tot = 0;
-    for (int c : cnt) tot += c;
+    for (size_t q = 0; q < cnt.size(); q += kMfCntStrideC) tot += cnt[q];
     *value = tot;
     return VDB_OK;
   }
