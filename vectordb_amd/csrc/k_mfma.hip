@@ -5,6 +5,7 @@
 #include "launch.h"
 #include "scan_mfma4.h"
 #include "scan_mfma5.h"
+#include "scan_mfma6.h"
 #include "scan_stream.h"
 
 namespace vdbk {
@@ -58,6 +59,10 @@ hipError_t mfma_prepare_device() {
   MF_TRY(hipFuncSetAttribute((const void*)scan_mfma_wide_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m5_smem_bytes()));
   MF_TRY(hipFuncSetAttribute((const void*)scan_mfma_wide_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m5_smem_bytes()));
   MF_TRY(hipFuncSetAttribute((const void*)scan_mfma_wide_kernel<1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m5_smem_bytes()));
+  MF_TRY(hipFuncSetAttribute((const void*)scan_mfma_wide16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m5_smem_bytes()));
+  MF_TRY(hipFuncSetAttribute((const void*)scan_mfma_wide16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m5_smem_bytes()));
+  MF_TRY(hipFuncSetAttribute((const void*)scan_mfma_wide16_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m5_smem_bytes()));
+  MF_TRY(hipFuncSetAttribute((const void*)scan_mfma_wide16_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m5_smem_bytes()));
   MF_TRY(stream_prepare_device());
   return hipSuccess;
 }
@@ -89,7 +94,18 @@ hipError_t mfma_search_launch(const MfSearchArgs& a, int* skipped_tiles) {
       return hipGetLastError();
     }
     const MfGrid g = mf_grid(a.n_cu, n_qt, pass_tiles, 1 << 30);
-    if (variant == 5) {
+    if (variant == 5 && a.shape16) {
+      if (mode == 0)
+        hipLaunchKernelGGL((scan_mfma_wide16_kernel<0>), dim3(n_qt * g.n_splits), dim3(kM5Threads), m5_smem_bytes(), st, rows, n_rows, qb16, b,
+                           n_qt, g.n_splits, g.tiles_per_split, (int)pass_tiles, stride, self0, g.xcd_map, (const float*)nullptr, dense,
+                           (int*)nullptr, (float*)nullptr, (int*)nullptr, 0, 0, 0);
+      else {
+        auto kern = (a.ablate & 1) ? scan_mfma_wide16_kernel<1, 1> : (a.ablate & 2) ? scan_mfma_wide16_kernel<1, 2> : scan_mfma_wide16_kernel<1, 0>;
+        hipLaunchKernelGGL(kern, dim3(n_qt * g.n_splits), dim3(kM5Threads), m5_smem_bytes(), st, rows, n_rows, qb16, b,
+                           n_qt, g.n_splits, g.tiles_per_split, (int)pass_tiles, stride, self0, g.xcd_map, (const float*)thr, dense,
+                           cand_cnt, cand_s, cand_i, cap, a.ablate, skip_n);
+      }
+    } else if (variant == 5) {
       if (mode == 0)
         hipLaunchKernelGGL((scan_mfma_wide_kernel<0>), dim3(n_qt * g.n_splits), dim3(kM5Threads), m5_smem_bytes(), st, rows, n_rows, qb16, b,
                            n_qt, g.n_splits, g.tiles_per_split, (int)pass_tiles, stride, self0, g.xcd_map, (const float*)nullptr, dense,
