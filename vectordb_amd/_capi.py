@@ -13,7 +13,8 @@ import os
 from typing import Optional
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-HIP_LIB_PATH = os.path.join(_PKG_DIR, "lib", "libvdb_hip.so")
+#: the HIP engine; VECTORDB_AMD_LIB names another build of the SAME library (kernel A/B runs), never another backend
+HIP_LIB_PATH = os.environ.get("VECTORDB_AMD_LIB") or os.path.join(_PKG_DIR, "lib", "libvdb_hip.so")
 
 VDB_F32 = 0
 VDB_BF16 = 1

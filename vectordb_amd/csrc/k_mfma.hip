@@ -90,7 +90,7 @@ hipError_t mfma_search_launch(const MfSearchArgs& a, int* skipped_tiles) {
   auto launch_pass = [&](int mode, long long pass_tiles, int stride, int skip_n) -> hipError_t {
     if (variant == 6) {
       stream_launch_pass(mode, rows, n_rows, qb16, b, (int)pass_tiles, stride, skip_n, self0, mode ? (const float*)thr : nullptr, dense,
-                         cand_cnt, cand_s, cand_i, cap, a.n_cu, a.stream_nt, a.stream_blocks_per_cu, st);
+                         cand_cnt, cand_s, cand_i, cap, a.n_cu, a.stream_nt, a.stream_blocks_per_cu, a.stream_lds, st);
       return hipGetLastError();
     }
     const MfGrid g = mf_grid(a.n_cu, n_qt, pass_tiles, 1 << 30);

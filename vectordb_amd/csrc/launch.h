@@ -27,7 +27,7 @@ bool launch_scan_any(bool bf16, const ScanArgs& a, int ld, int e, bool nt);
 struct MfSearchArgs {
   const unsigned char* rows_bf16; int n_rows; const float* qn; int b; int kk; int self0;
   int n_cu; int variant;           // 4 = 256x128 warp-specialised, 5 = 256x256 wide tile, 6 = streaming (<= 64 queries)
-  int cap; int split_x1000; int skip_sample; int force_fallback; int ablate; int stream_nt; int stream_blocks_per_cu; int shape16;
+  int cap; int split_x1000; int skip_sample; int force_fallback; int ablate; int stream_nt; int stream_blocks_per_cu; int shape16; int stream_lds;
   unsigned char* qb16;             // [b_pad][768] bf16
   float* cand_s; int* cand_i;      // [b][cap]
   int* cand_cnt;                   // [b] counters, kMfCntStrideC ints apart, + the overflow flag behind them

@@ -21,6 +21,12 @@
 // The work unit is a 16-row slice of one of the protocol's 256-row tiles, dealt round-robin to the waves
 // of the grid, so that the chip walks the corpus as one contiguous window (like the GEMV scan).
 // Algorithmic bytes per final pass = n_rows * 1536: the kernel is priced against the HBM roofline.
+//
+// Two forms.  scan_stream_kernel (this one, "register form"): fragments straight from global_load_dwordx4 — no LDS
+// for the corpus at all, but its 64-byte row pieces are HALF cache lines, which the memory path delivers ~13 %
+// slower (6.1 TB/s in the final pass at 10M rows).  scan_stream_lds_kernel (below, the default for the append
+// passes): whole lines by LDS-DMA into a per-wave ring, fragments read back transposed — 6.6-6.8 TB/s; measured per
+// step at 10M rows: 2.47 ms (B = 4), 2.50 (16), 2.48-2.58 (32), 2.42-2.49 (64) against 2.66-2.73 for the register form.
 #pragma once
 #include "scan_mfma3.h"
 
@@ -181,6 +187,175 @@ __global__ __launch_bounds__(kStThreads, (NQ <= 2 ? 4 : 2)) void scan_stream_ker
   }
 }
 
+// ---- the same kernel with the corpus transposed through a per-wave LDS ring (whole cache lines) ----------------
+// The register form above reads 64-byte row pieces: half cache lines, which the memory path delivers ~13 % slower than
+// whole ones.  Here a wave brings its 16 rows in slabs of 16 x 128 bytes = two coalesced LDS-DMA instructions
+// (global_load_lds_dwordx4: 8 lanes per row-line, 8 rows per instruction, no VGPR round trip) into a private ring of
+// kStSlabs slabs, and reads the A fragments back in MFMA layout with ds_read_b128.  LDS position (16-byte units) of
+// (row m, chunk ch) inside a slab: m*8 + (ch ^ ((m>>1)&7)) — the swizzle is applied on the SOURCE address of each DMA
+// lane, and makes the 16 lanes of a fragment read fall into 16 different bank groups.  No barrier: a wave only ever
+// reads what its own DMA wrote, behind a counted s_waitcnt vmcnt (the younger slabs of the ring stay in flight).
+constexpr int kStSlabBytes = kStRows * 128;          // 2 KiB: 16 rows x one 128-byte line = two k32 steps
+constexpr int kStSlabsPerTile = kMfRowBytes / 128;   // 12
+// ring depth per wave: 6 slabs (12 KiB, 10 KiB in flight) beside <= 32 queries; 3 beside 33..64 (their image takes 97 KiB)
+#ifndef VDB_ST_RING
+#define VDB_ST_RING 6
+#endif
+__host__ __device__ constexpr int st_ring_slabs(int nq) { return nq <= 2 ? VDB_ST_RING : 3; }
+__host__ __device__ constexpr size_t st_lds_smem_bytes(int nq) { return st_smem_bytes(nq) + (size_t)kStWaves * st_ring_slabs(nq) * kStSlabBytes; }
+
+template <bool NT>
+__device__ __forceinline__ void st_glds16(const unsigned char* gptr, unsigned char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, NT ? 2 : 0);
+}
+
+template <int MODE, int NQ, bool NT>
+__global__ __launch_bounds__(kStThreads, 2) void scan_stream_lds_kernel(
+    const unsigned char* __restrict__ rows, int n_rows, const unsigned char* __restrict__ qb16, int b,
+    int n_pass_tiles, int tile_stride, int skip_n, int self0, const float* __restrict__ thr_in,
+    float* __restrict__ dense, int* __restrict__ cand_cnt, float* __restrict__ cand_s, int* __restrict__ cand_i, int cap) {
+  extern __shared__ __align__(16) unsigned char smem[];   // [query image][8 waves x kStSlabs slabs]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 15;
+  const int c = lane >> 4;
+
+  for (int i = tid; i < NQ * 16 * (kMfRowBytes / 16); i += kStThreads) {
+    const int qr = i / (kMfRowBytes / 16), ch = i - qr * (kMfRowBytes / 16);
+    *reinterpret_cast<st_u32x4*>(smem + qr * kStQStride + ch * 16) =
+        *reinterpret_cast<const st_u32x4*>(qb16 + (size_t)qr * kMfRowBytes + ch * 16);
+  }
+  __syncthreads();   // the only barrier
+
+  float thr[NQ];
+  int thr_bits[NQ];
+#pragma unroll
+  for (int nq = 0; nq < NQ; ++nq) {
+    thr[nq] = (MODE == 1 && thr_in) ? thr_in[min(nq * 16 + m, b - 1)] : -INFINITY;
+    thr_bits[nq] = thr[nq] > 0.f ? __float_as_int(thr[nq]) : (int)0x80000000;
+  }
+
+  const long long n_units = (long long)n_pass_tiles * kStSub;
+  const long long nw = (long long)gridDim.x * kStWaves;
+  long long u = (long long)blockIdx.x * kStWaves + w;
+  if (u >= n_units) return;
+  auto unit_row0 = [&](long long uu) -> int {
+    const int t = (int)(uu / kStSub), sub = (int)(uu - (long long)t * kStSub);
+    return pass_tile(t, tile_stride, skip_n) * kMfBM + sub * kStRows;
+  };
+  constexpr int kStSlabs = st_ring_slabs(NQ);
+  static_assert(kStSlabsPerTile % kStSlabs == 0, "ring slots must be compile-time");
+  unsigned char* ring = smem + st_smem_bytes(NQ) + w * (kStSlabs * kStSlabBytes);
+  // DMA source offsets of this lane inside a tile, for the slab's two instructions (rows 0-7, rows 8-15)
+  unsigned src_off[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int mr = 8 * i + (lane >> 3), ch = (lane & 7) ^ ((mr >> 1) & 7);
+    src_off[i] = (unsigned)(mr * kMfRowBytes + ch * 16);
+  }
+  // fragment read offsets inside a slab, k32 step t of the slab
+  int rd[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) rd[t] = (m * 8 + ((4 * t + c) ^ ((m >> 1) & 7))) * 16;
+  const unsigned char* qfrag = smem + m * kStQStride + c * 16;
+
+  int row0 = unit_row0(u);
+  const unsigned char* pc = rows + (size_t)row0 * kMfRowBytes;   // wave-uniform tile base
+  auto issue_slab = [&](const unsigned char* tile, int seg, int slot) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) st_glds16<NT>(tile + seg * 128 + src_off[i], ring + slot * kStSlabBytes + i * 1024);
+  };
+#pragma unroll
+  for (int j = 0; j < kStSlabs; ++j) issue_slab(pc, j, j);
+
+  for (;;) {
+    const long long un = u + nw;
+    const bool has_next = un < n_units;
+    const int row0n = has_next ? unit_row0(un) : row0;   // the last unit refills from itself: harmless, never consumed
+    const unsigned char* pn = rows + (size_t)row0n * kMfRowBytes;
+    f32x4_t acc[NQ];
+#pragma unroll
+    for (int nq = 0; nq < NQ; ++nq) acc[nq] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    int qoff = 0;
+    asm volatile("" : "+v"(qoff));   // keeps the (loop-invariant) query fragment reads inside the loop, see above
+#pragma unroll
+    for (int j = 0; j < kStSlabsPerTile; ++j) {
+      constexpr int kYounger = 2 * (kStSlabs - 1);   // DMA instructions of the younger slabs still allowed in flight
+      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kYounger) : "memory");   // slab j has landed
+      const unsigned char* slab = ring + (j % kStSlabs) * kStSlabBytes;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(slab + rd[t]);
+#pragma unroll
+        for (int nq = 0; nq < NQ; ++nq) {
+          const bf16x8_t q = *reinterpret_cast<const bf16x8_t*>(qfrag + qoff + nq * 16 * kStQStride + (2 * j + t) * 64);
+          acc[nq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, q, acc[nq], 0, 0, 0);
+        }
+      }
+      // the fragments of this slab are in registers (the MFMAs above waited for them): its slot can be refilled
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const int jn = j + kStSlabs;
+      if (jn < kStSlabsPerTile) issue_slab(pc, jn, j % kStSlabs); else issue_slab(pn, jn - kStSlabsPerTile, j % kStSlabs);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- epilogue: as in scan_stream_kernel ----
+    const int t_local = (int)(u / kStSub), sub = (int)(u - (long long)t_local * kStSub);
+    if (MODE == 0) {
+#pragma unroll
+      for (int nq = 0; nq < NQ; ++nq) {
+        const int qg = nq * 16 + m;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int rloc = sub * kStRows + 4 * c + reg;
+          const int row = row0 + 4 * c + reg;
+          const bool ok = (row < n_rows) && !(self0 >= 0 && row == self0 + qg);
+          if (qg < b) dense[(size_t)qg * kMf3DenseLd + t_local * kMfBM + rloc] = ok ? acc[nq][reg] : -INFINITY;
+        }
+      }
+    } else {
+      bool any = false;
+#pragma unroll
+      for (int nq = 0; nq < NQ; ++nq) {
+        const int mx = max(max(__float_as_int(acc[nq][0]), __float_as_int(acc[nq][1])),
+                           max(__float_as_int(acc[nq][2]), __float_as_int(acc[nq][3])));
+        any = any || (mx >= thr_bits[nq]);
+      }
+      if (__ballot(any) != 0ull) {
+        int pos[NQ][4];
+#pragma unroll
+        for (int nq = 0; nq < NQ; ++nq) {
+          const int qg = nq * 16 + m;
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) {
+            const int row = row0 + 4 * c + reg;
+            const bool pass = (acc[nq][reg] >= thr[nq]) && (row < n_rows) && (qg < b) && !(self0 >= 0 && row == self0 + qg);
+            pos[nq][reg] = pass ? atomicAdd(&cand_cnt[qg * kMfCntStride], 1) : cap;
+          }
+        }
+        // the atomics share the counter with the DMA loads and may return out of order with them: drain, so that the
+        // counted waits of the next tile count loads only
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int nq = 0; nq < NQ; ++nq) {
+          const int qg = nq * 16 + m;
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg)
+            if (pos[nq][reg] < cap) {
+              cand_s[(size_t)qg * cap + pos[nq][reg]] = acc[nq][reg];
+              cand_i[(size_t)qg * cap + pos[nq][reg]] = row0 + 4 * c + reg;
+            }
+        }
+      }
+    }
+    if (!has_next) break;
+    u = un; row0 = row0n; pc = pn;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing refills must land before the LDS is handed on
+}
+
 // ---- host side --------------------------------------------------------------------------------------
 inline int st_blocks(int b) { const int nq = (b + 15) / 16; return nq <= 1 ? 1 : nq <= 2 ? 2 : 4; }
 
@@ -190,15 +365,30 @@ inline hipError_t stream_prepare_device() {
   if ((e = hipFuncSetAttribute((const void*)scan_stream_kernel<MODE, NQ, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)st_smem_bytes(NQ))) != hipSuccess) return e;
   ST_ATTR(0, 4, false) ST_ATTR(1, 4, false) ST_ATTR(1, 4, true)
 #undef ST_ATTR
+#define ST_ATTR(MODE, NQ, NT) \
+  if ((e = hipFuncSetAttribute((const void*)scan_stream_lds_kernel<MODE, NQ, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)st_lds_smem_bytes(NQ))) != hipSuccess) return e;
+  ST_ATTR(1, 1, false) ST_ATTR(1, 1, true) ST_ATTR(1, 2, false) ST_ATTR(1, 2, true) ST_ATTR(1, 4, false) ST_ATTR(1, 4, true)
+#undef ST_ATTR
   return hipSuccess;
 }
 
 // one pass over n_pass_tiles protocol tiles (pass_tile(i, stride, skip_n)); mode 0 = dense sample, 1 = append
 inline void stream_launch_pass(int mode, const unsigned char* rows, int n_rows, const unsigned char* qb16, int b, int n_pass_tiles,
                                int tile_stride, int skip_n, int self0, const float* thr, float* dense, int* cand_cnt,
-                               float* cand_s, int* cand_i, int cap, int n_cu, int nt, int blocks_per_cu, hipStream_t st) {
+                               float* cand_s, int* cand_i, int cap, int n_cu, int nt, int blocks_per_cu, int lds_ring, hipStream_t st) {
   const int nq = st_blocks(b);
   const long long units = (long long)n_pass_tiles * kStSub;
+  if (lds_ring && mode == 1 && (nq <= 2 || lds_ring >= 2)) {   // append passes: whole cache lines through the per-wave LDS ring
+    const int grid = (int)std::max<long long>(1, std::min<long long>((long long)n_cu, (units + kStWaves - 1) / kStWaves));
+#define STL_LAUNCH(NQ, NT)                                                                                                          \
+  hipLaunchKernelGGL((scan_stream_lds_kernel<1, NQ, NT>), dim3(grid), dim3(kStThreads), st_lds_smem_bytes(NQ), st, rows, n_rows, qb16, b, \
+                     n_pass_tiles, tile_stride, skip_n, self0, thr, dense, cand_cnt, cand_s, cand_i, cap)
+    if (nq == 1) { if (nt) STL_LAUNCH(1, true); else STL_LAUNCH(1, false); }
+    else if (nq == 2) { if (nt) STL_LAUNCH(2, true); else STL_LAUNCH(2, false); }
+    else { if (nt) STL_LAUNCH(4, true); else STL_LAUNCH(4, false); }
+#undef STL_LAUNCH
+    return;
+  }
   const int per_cu = blocks_per_cu > 0 ? blocks_per_cu : (nq <= 2 ? 2 : 1);
   const int grid = (int)std::max<long long>(1, std::min<long long>((long long)n_cu * per_cu, (units + kStWaves - 1) / kStWaves));
 #define ST_LAUNCH(MODE, NQ, NT)                                                                                                   \

@@ -79,8 +79,9 @@ struct vdb {
   bool mfma_attr_set = false;    // dynamic-LDS limits of the MFMA kernels raised on this handle's device
   int mfma_cost_model = 1;       // 0: every supported batch >= batch_mfma_min_b takes the MFMA path (tests)
   int mfma_ablate = 0;   // diagnostic: skip parts of the MFMA kernel (wrong results, timing only)
-  int stream_nt = 0;     // the streaming kernel's corpus loads: 0 = plain, 1 = non-temporal
+  int stream_nt = 1;     // the streaming kernel's append passes: 1 = non-temporal corpus loads (right for the LDS ring: whole lines, read once; wrong for the register form's half lines)
   int stream_blocks_per_cu = 0;   // 0 = the kernel's own choice
+  int stream_lds = 2;             // the streaming kernel's append passes through the per-wave LDS ring (whole cache lines): 0 = never (register form), 1 = up to 32 queries, 2 = always
   int mfma_shape16 = 1;           // the wide-tile kernel on v_mfma_f32_16x16x32_bf16 (scan_mfma6.h; 1.3-1.9 % faster, interleaved A/B) instead of 32x32x16 (scan_mfma5.h)
   // workspaces (grown on demand)
   DevBuf w_q, w_part_s, w_part_i, w_part2_s, w_part2_i, w_stage, w_out_i, w_out_d, w_idx, w_mfma;
@@ -305,7 +306,7 @@ int mfma_search(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
   a.rows_bf16 = (const unsigned char*)h->rows_bf16; a.n_rows = n_rows; a.qn = qn; a.b = b; a.kk = kk;
   a.self0 = self_row0 >= 0 ? (int)self_row0 : -1;
   a.n_cu = h->n_cu; a.variant = h->mfma_variant; a.cap = cap; a.split_x1000 = h->mfma_split_x1000;
-  a.skip_sample = h->mfma_skip_sample; a.force_fallback = h->mfma_force_fallback; a.ablate = h->mfma_ablate; a.stream_nt = h->stream_nt; a.stream_blocks_per_cu = h->stream_blocks_per_cu; a.shape16 = h->mfma_shape16;
+  a.skip_sample = h->mfma_skip_sample; a.force_fallback = h->mfma_force_fallback; a.ablate = h->mfma_ablate; a.stream_nt = h->stream_nt; a.stream_blocks_per_cu = h->stream_blocks_per_cu; a.shape16 = h->mfma_shape16; a.stream_lds = h->stream_lds;
   a.qb16 = (unsigned char*)h->w_mfma.p;
   a.cand_s = (float*)h->w_cand_s.p; a.cand_i = (int*)h->w_cand_i.p; a.cand_cnt = (int*)h->w_cand_cnt.p;
   a.thr = (float*)h->w_thr.p; a.dense = (float*)h->w_dense.p;
@@ -333,20 +334,20 @@ int mfma_search(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
 }
 
 // Which path serves a bf16 768-d batch faster?  Coefficients measured on MI355X (10M and 1M rows, round 2):
-// a GEMV pass costs a launch (~12 us) plus the corpus at ~6.7 TB/s, times 1.0 / 1.10 / 1.64 for 1 / 2 / 4
+// a GEMV pass costs a launch (~12 us) plus the corpus at ~6.7 TB/s, times 1.0 / 1.06 / 1.64 for 1 / 2 / 4
 // queries per pass (b = 3 runs as 2 + 1).  The batched path costs ~110 us of launches (dense sample, selects,
-// append passes) plus, per row: the streaming kernel (<= 64 queries) the corpus at ~6.0 TB/s (its 64-byte row
-// pieces are half cache lines: the memory path takes ~13 % fewer bytes per second than from whole lines); the
-// tiled kernels 0.25 ns per 128-query tile or 0.36 (+0.05) ns per 256-query tile.
-// Measured at 10M rows: b = 2 GEMV 2.42-2.51 ms vs streaming 2.67; b = 4 3.70 vs 2.66; b = 64 58.6 vs 2.70;
-// b = 128 tiled 3.29.
+// append passes) plus, per row: the streaming kernel (<= 64 queries) the corpus at ~6.6 TB/s (whole lines through
+// its LDS ring; 6.0 in the register form); the tiled kernels 0.25 ns per 128-query tile or 0.36 (+0.05) ns per
+// 256-query tile.
+// Measured at 10M rows: b = 2 GEMV 2.34 ms vs streaming 2.45; b = 4 3.70 vs 2.46; b = 64 58.6 vs 2.45;
+// b = 65 tiled 3.03; b = 128 3.25.
 bool mfma_is_faster(int b, int n_rows, int variant_opt) {
   const double pass = 12e-6 + (double)n_rows * kMfRowBytesC / 6.7e12;
   const int r = b & 3;
-  const double gemv = pass * (1.64 * (b >> 2) + (r == 3 ? 2.10 : r == 2 ? 1.10 : r == 1 ? 1.0 : 0.0));
+  const double gemv = pass * (1.64 * (b >> 2) + (r == 3 ? 2.06 : r == 2 ? 1.06 : r == 1 ? 1.0 : 0.0));
   const MfPlan pl = mfma_plan(b, n_rows, 256, variant_opt);
   double mfma;
-  if (pl.variant == 6) mfma = 110e-6 + (double)n_rows * kMfRowBytesC / 6.0e12;
+  if (pl.variant == 6) mfma = 110e-6 + (double)n_rows * kMfRowBytesC / 6.6e12;
   else if (pl.variant == 5) mfma = 100e-6 + (double)n_rows * (0.36e-9 * pl.n_qt + 0.05e-9);
   else mfma = 100e-6 + (double)n_rows * 0.25e-9 * pl.n_qt;
   return mfma < gemv;
@@ -1319,6 +1320,7 @@ int vdb_set_option(vdb_t* h, const char* name, int64_t value) {
   if (!strcmp(name, "scan_nt_loads")) { h->scan_nt_loads = value != 0; return VDB_OK; }
   if (!strcmp(name, "stream_nt_loads")) { h->stream_nt = value != 0; return VDB_OK; }
   if (!strcmp(name, "mfma_shape16")) { h->mfma_shape16 = value != 0; return VDB_OK; }
+  if (!strcmp(name, "stream_lds_ring")) { if (value < 0 || value > 2) return fail(h, VDB_ERR_ARG, "stream_lds_ring must be 0, 1 (<= 32 queries) or 2 (<= 64)"); h->stream_lds = (int)value; return VDB_OK; }
   if (!strcmp(name, "stream_blocks_per_cu")) { if (value < 0 || value > 8) return fail(h, VDB_ERR_ARG, "stream_blocks_per_cu must be in [0,8]"); h->stream_blocks_per_cu = (int)value; return VDB_OK; }
   if (!strcmp(name, "mfma_ablate")) { h->mfma_ablate = (int)value; return VDB_OK; }
   if (!strcmp(name, "mfma_variant")) {
