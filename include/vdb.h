@@ -82,7 +82,7 @@ int vdb_create(vdb_t** out, int dim, int dtype, int keep_f32_for_rerank, int dev
  * stream; each shard's finish kernel stores its k results straight into shard 0's gather buffer (over xGMI when peer
  * access is available, a peer copy otherwise) and one merge kernel on shard 0 ranks the n_devices lists.  No host
  * synchronisation inside vdb_search_dev; queries and outputs of the *_dev calls live on shard 0's device.
- * Served on a sharded handle: reserve, add, add_synth, count, search, search_dev, fetch, save, last_timing,
+ * Served on a sharded handle: reserve, add, add_synth, count, search, search_fetch, search_dev, fetch, save, last_timing,
  * timing_stats, set_option (applied to every shard), get_stat.  Everything else returns VDB_ERR_STATE. */
 int vdb_create_sharded(vdb_t** out, int dim, int dtype, int keep_f32_for_rerank, const int* device_ids, int n_devices);
 
@@ -131,6 +131,14 @@ int vdb_count(vdb_t* h, int64_t* n);
  * repairs), so its result does not depend on the batch size either. */
 int vdb_search(vdb_t* h, const float* queries_host, int b, int k, int rerank_kprime,
                int64_t* out_idx_host, float* out_dist_host);
+
+/* vdb_search that also returns the STORED rows of the hits: replaces collection.query(..., include=[..., "embeddings"])
+ * as the reference's hot call makes it (src/vectordb.py:259-264 asks for 30 hits with their embeddings and re-scores
+ * them, :282-308).  out_rows_host: b x k x dim fp32, the normalised fp32 row of every hit (zeros behind an idx of -1),
+ * gathered on the device behind the search and returned in the same copy — one round trip instead of a search and a
+ * vdb_fetch. */
+int vdb_search_fetch(vdb_t* h, const float* queries_host, int b, int k, int rerank_kprime,
+                     int64_t* out_idx_host, float* out_dist_host, float* out_rows_host);
 
 /* Same with device-resident queries and outputs, asynchronous on `stream`
  * (a hipStream_t; NULL = the default (null) stream, as everywhere in HIP).  The

@@ -344,6 +344,19 @@ int vdb_search(vdb_t* h, const float* queries, int b, int k, int kp, int64_t* ou
   if (!h) return VDB_ERR_ARG;
   return search_all(h, queries, b, k, kp, NULL, out_idx, out_dist);
 }
+int vdb_search_fetch(vdb_t* h, const float* queries, int b, int k, int kp, int64_t* out_idx, float* out_dist, float* out_rows) {
+  if (!h) return VDB_ERR_ARG;
+  if (b > 0 && !out_rows) return fail(h, VDB_ERR_ARG, "search_fetch: NULL rows buffer");
+  int rc = search_all(h, queries, b, k, kp, NULL, out_idx, out_dist);
+  if (rc) return rc;
+  for (int64_t j = 0; j < (int64_t)b * k; ++j) {
+    float* o = out_rows + (size_t)j * h->dim;
+    int64_t r = out_idx[j] < 0 ? -1 : out_idx[j] - h->row_offset;
+    for (int c = 0; c < h->dim; ++c)
+      o[c] = r < 0 ? 0.f : h->keep_f32 ? h->rows[r * h->dim + c] : bf16_to_f32(h->rows16[r * h->dim + c]);
+  }
+  return VDB_OK;
+}
 int vdb_search_dev(vdb_t* h, const float* q, int b, int k, int kp, int64_t* oi, float* od, void* stream) {
   (void)stream;
   return vdb_search(h, q, b, k, kp, oi, od);

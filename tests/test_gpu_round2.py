@@ -341,3 +341,27 @@ def test_pending_two_phase_scan_blocks_other_searches(hip_lib, oracle_mod):
     assert np.array_equal(oi.cpu().numpy(), ref_i) and np.array_equal(od.cpu().numpy(), ref_d)
     ix.search(q.cpu().numpy(), 5)          # and the handle is usable again
     ix.close()
+
+
+def test_search_fetch_returns_the_hits_rows_in_one_call(hip_lib, oracle_mod, corpus33k):
+    """vdb_search_fetch == vdb_search + vdb_fetch: same ids and distances, rows bit-identical to the stored rows; zero
+    rows behind -1 padding; fp32 and bf16+rerank stores; a sharded handle (rows come from their shards)."""
+    n, dim, spec, rows, queries = corpus33k
+    for dtype, kp, devices in (("f32", 0, None), ("bf16", 40, None), ("bf16", 40, [0, 0, 0])):
+        ix = FlatIndex(dim, dtype, True, devices=devices)
+        if devices:
+            ix.reserve(n)
+        ix.add_synth(0, n, spec)
+        for b, k in ((1, 30), (5, 10)):
+            i0, d0 = ix.search(queries[:b], k, kp)
+            i1, d1, r1 = ix.search_fetch(queries[:b], k, kp)
+            assert np.array_equal(i0, i1) and np.array_equal(d0, d1)
+            assert np.array_equal(r1.reshape(b * k, dim), ix.fetch(i1.reshape(-1)))
+            assert np.max(np.abs(r1.reshape(b * k, dim) - rows[i1.reshape(-1)])) < 1e-6
+        ix.close()
+    tiny = FlatIndex(64, "f32")
+    rng = np.random.default_rng(0)
+    tiny.add(rng.standard_normal((3, 64)).astype(np.float32))
+    i, d, r = tiny.search_fetch(rng.standard_normal((2, 64)).astype(np.float32), 5)
+    assert np.all(i[:, 3:] == -1) and np.all(r[:, 3:] == 0) and np.all(np.abs(np.linalg.norm(r[:, :3], axis=2) - 1) < 1e-5)
+    tiny.close()

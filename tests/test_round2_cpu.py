@@ -128,6 +128,25 @@ def test_sharded_handle_rules_on_the_oracle_twin(oracle_lib, oracle_mod, tmp_pat
         ix.close()
 
 
+def test_search_fetch_on_the_oracle_twin_and_through_the_collection(oracle_lib, tmp_path):
+    rng = np.random.default_rng(5)
+    rows = rng.standard_normal((50, 16)).astype(np.float32)
+    ix = FlatIndex(16, "f32", lib=oracle_lib)
+    ix.add(rows)
+    q = rows[[4, 40]] + 0.01
+    i0, d0 = ix.search(q, 60)
+    i1, d1, r1 = ix.search_fetch(q, 60)
+    assert np.array_equal(i0, i1) and np.array_equal(d0, d1)
+    assert np.array_equal(r1[:, :50].reshape(-1, 16), ix.fetch(i1[:, :50].reshape(-1))) and np.all(r1[:, 50:] == 0)
+    ix.close()
+    col = _col(PersistentClient(path=str(tmp_path), lib=oracle_lib))
+    col.add(embeddings=rows, ids=[f"i{j}" for j in range(50)])
+    res = col.query(query_embeddings=q, n_results=3, include=["embeddings", "distances"])
+    assert [r[0] for r in res["ids"]] == ["i4", "i40"]
+    for j, src in enumerate((4, 40)):
+        assert np.allclose(res["embeddings"][j][0], rows[src] / np.linalg.norm(rows[src]), atol=1e-6)
+
+
 def test_batched_best_match_maps_an_empty_answer_to_none(oracle_lib):
     """A product whose embedding is not finite gets no row back from the engine (idx -1 / +inf): it must read
     (None, -1.0) like the reference's loop (generate_best_usda_matches.py:116-143), not the last USDA code."""

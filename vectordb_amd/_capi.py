@@ -23,7 +23,7 @@ VDB_MAX_K = 1024
 #: every symbol include/vdb.h declares (tests check the built library exports all of them)
 SYMBOLS = (
     "vdb_create", "vdb_create_sharded", "vdb_load_sharded", "vdb_search_dev_noalloc", "vdb_destroy", "vdb_last_error", "vdb_reserve", "vdb_set_row_offset",
-    "vdb_add", "vdb_add_dev", "vdb_count", "vdb_search", "vdb_search_dev", "vdb_search_masked", "vdb_search_masked_dev",
+    "vdb_add", "vdb_add_dev", "vdb_count", "vdb_search", "vdb_search_fetch", "vdb_search_dev", "vdb_search_masked", "vdb_search_masked_dev",
     "vdb_search_scan_dev", "vdb_search_finish_dev",
     "vdb_merge_topk_dev",
     "vdb_selfjoin", "vdb_fetch", "vdb_save", "vdb_load", "vdb_last_timing", "vdb_timing_stats", "vdb_set_option", "vdb_get_stat",
@@ -66,6 +66,7 @@ def _declare(lib: C.CDLL) -> C.CDLL:
     lib.vdb_add_dev.argtypes = [vp, pf, i64]
     lib.vdb_count.argtypes = [vp, C.POINTER(i64)]
     lib.vdb_search.argtypes = [vp, pf, i32, i32, i32, pi64, pf]
+    lib.vdb_search_fetch.argtypes = [vp, pf, i32, i32, i32, pi64, pf, pf]
     lib.vdb_search_dev.argtypes = [vp, pf, i32, i32, i32, pi64, pf, vp]
     lib.vdb_search_masked.argtypes = [vp, pf, i32, i32, i32, vp, i64, pi64, pf]
     lib.vdb_search_masked_dev.argtypes = [vp, pf, i32, i32, i32, vp, i64, pi64, pf, vp]

@@ -225,6 +225,7 @@ class Collection:
 
         rows: List[np.ndarray]
         dists: List[np.ndarray]
+        hit_rows = None
         if total == 0:
             rows = [np.zeros(0, np.int64) for _ in range(b)]
             dists = [np.zeros(0, np.float32) for _ in range(b)]
@@ -232,7 +233,11 @@ class Collection:
             rows, dists = self._query_filtered(q, n_results, where)
         else:
             k = min(n_results, total)           # chromadb clamps n_results to the collection size
-            idx, dist = self._index.search(q, k, self._kprime(k))
+            if "embeddings" in include and b * k * (self._dim or 0) * 4 <= (256 << 20):
+                # the reference's hot call (src/vectordb.py:259-264): hits AND their stored rows in one round trip
+                idx, dist, hit_rows = self._index.search_fetch(q, k, self._kprime(k))
+            else:
+                idx, dist = self._index.search(q, k, self._kprime(k))
             rows = [idx[i][idx[i] >= 0] for i in range(b)]
             dists = [dist[i][: len(rows[i])] for i in range(b)]
 
@@ -248,9 +253,12 @@ class Collection:
         if "documents" in include:
             out["documents"] = [[docs_[r] for r in rl] for rl in row_lists]
         if "embeddings" in include:
-            flat = self._stored_rows(np.concatenate(rows) if rows else np.zeros(0, np.int64))   # one fetch for the batch
-            cuts = np.cumsum([0] + [len(rr) for rr in rows])
-            out["embeddings"] = [self._format_embeddings(flat[cuts[i]:cuts[i + 1]]) for i in range(b)]
+            if hit_rows is not None:
+                out["embeddings"] = [self._format_embeddings(hit_rows[i, : len(rows[i])]) for i in range(b)]
+            else:
+                flat = self._stored_rows(np.concatenate(rows) if rows else np.zeros(0, np.int64))   # one fetch for the batch
+                cuts = np.cumsum([0] + [len(rr) for rr in rows])
+                out["embeddings"] = [self._format_embeddings(flat[cuts[i]:cuts[i + 1]]) for i in range(b)]
         return out
 
     def _query_filtered(self, q: np.ndarray, n_results: int, where: dict):

@@ -312,6 +312,21 @@ __global__ void gather_rows_kernel(const float* __restrict__ rows_f32, const uin
   }
 }
 
+// rows of a search result: idx holds GLOBAL indices (local + row_offset) or -1 -> dense fp32 [n][dim], zeros behind -1
+__global__ void gather_result_rows_kernel(const float* __restrict__ rows_f32, const uint16_t* __restrict__ rows_bf16,
+                                          int ld, int dim, const long long* __restrict__ idx, long long n,
+                                          long long row_offset, float* __restrict__ out) {
+  const int lane = lane_id();
+  const long long w = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const long long nw = (long long)gridDim.x * (blockDim.x >> 6);
+  for (long long r = w; r < n; r += nw) {
+    const long long g = idx[r];
+    const long long src = g - row_offset;
+    for (int c = lane; c < dim; c += 64)
+      out[r * dim + c] = g < 0 ? 0.f : rows_f32 ? rows_f32[src * ld + c] : __uint_as_float((uint32_t)rows_bf16[src * ld + c] << 16);
+  }
+}
+
 __global__ void fill_empty_kernel(long long* __restrict__ out_idx, float* __restrict__ out_dist, long long n) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) { out_idx[i] = -1; out_dist[i] = INFINITY; }

@@ -866,21 +866,27 @@ int vdb_search_finish_dev(vdb_t* h, int slot, int64_t* out_idx_dev, float* out_d
   return VDB_OK;
 }
 
-int vdb_search(vdb_t* h, const float* queries_host, int b, int k, int kp, int64_t* out_idx, float* out_dist) {
-  if (!h) return VDB_ERR_ARG;
+namespace {
+// vdb_search and vdb_search_fetch: host queries in, host results out; with out_rows also the stored rows of the hits
+// (b x k x dim fp32, zero rows behind a -1 index), gathered on the device right behind the search and brought back in
+// the same copy.
+int search_host(vdb_t* h, const float* queries_host, int b, int k, int kp, int64_t* out_idx, float* out_dist, float* out_rows) {
   int rc = check_search_args(h, queries_host, b, k, kp, out_idx, out_dist);
   if (rc) return rc;
   if (b == 0) return VDB_OK;
   if ((rc = set_device(h))) return rc;
   const size_t qbytes = (size_t)b * h->dim * 4, ibytes = (size_t)b * k * 8, dbytes = (size_t)b * k * 4;
+  const size_t rbytes = out_rows && !is_sharded(h) ? (size_t)b * k * h->dim * 4 : 0;
+  if (rbytes > ((size_t)1 << 30)) return fail(h, VDB_ERR_ARG, "search_fetch: more than 1 GiB of rows per call (search, then vdb_fetch in pieces)");
   if ((rc = ensure(h, h->w_stage, qbytes))) return rc;
-  if ((rc = ensure(h, h->w_out_i, ibytes + dbytes))) return rc;    // [idx | dist] in one buffer: one copy back
+  if ((rc = ensure(h, h->w_out_i, ibytes + dbytes + rbytes))) return rc;    // [idx | dist | rows] in one buffer: one copy back
   int64_t* d_idx = (int64_t*)h->w_out_i.p;
   float* d_dist = (float*)((char*)h->w_out_i.p + ibytes);
+  float* d_rows = (float*)((char*)h->w_out_i.p + ibytes + dbytes);
   // Small calls (every reference call site is batch 1) go through pinned staging: a copy from or to pageable
   // memory is staged by the runtime and costs ~10 us each at any size; three of them were half of a
   // 41 us query against a 14 777-row store.
-  const size_t pin_need = qbytes + ibytes + dbytes;
+  const size_t pin_need = qbytes + ibytes + dbytes + rbytes;
   bool pinned = pin_need <= ((size_t)1 << 20);
   if (pinned && h->pin_bytes < pin_need) {
     if (h->pin) { HIP_TRY(h, hipStreamSynchronize(h->stream)); HIP_TRY(h, hipHostFree(h->pin)); h->pin = nullptr; h->pin_bytes = 0; }
@@ -900,19 +906,50 @@ int vdb_search(vdb_t* h, const float* queries_host, int b, int k, int kp, int64_
     float* qn = nullptr;
     if ((rc = prep_queries(h, (const float*)h->w_stage.p, b, h->stream, &qn))) return rc;
     if ((rc = search_core(h, qn, b, k, kp, -1, d_idx, d_dist, h->stream))) return rc;
+    if (rbytes) {
+      const long long nr = (long long)b * k;
+      hipLaunchKernelGGL(gather_result_rows_kernel, dim3((int)std::min<long long>((nr + 3) / 4, (long long)h->n_cu * 8)), dim3(256), 0, h->stream,
+                         h->keep_f32 ? h->rows_f32 : nullptr, h->rows_bf16, h->ld, h->dim, (const long long*)d_idx, nr,
+                         (long long)h->row_offset, d_rows);
+      HIP_TRY(h, hipGetLastError());
+    }
   }
   if (pinned) {
     char* back = (char*)h->pin + qbytes;
-    HIP_TRY(h, hipMemcpyAsync(back, h->w_out_i.p, ibytes + dbytes, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(back, h->w_out_i.p, ibytes + dbytes + rbytes, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     memcpy(out_idx, back, ibytes);
     memcpy(out_dist, back + ibytes, dbytes);
+    if (rbytes) memcpy(out_rows, back + ibytes + dbytes, rbytes);
   } else {
     HIP_TRY(h, hipMemcpyAsync(out_idx, d_idx, ibytes, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipMemcpyAsync(out_dist, d_dist, dbytes, hipMemcpyDeviceToHost, h->stream));
+    if (rbytes) HIP_TRY(h, hipMemcpyAsync(out_rows, d_rows, rbytes, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
   }
+  if (out_rows && is_sharded(h)) {   // the rows live on their shards: fetch them by global index (zero rows behind -1)
+    const int64_t nr = (int64_t)b * k;
+    std::vector<int64_t> ok;
+    std::vector<int64_t> pos;
+    for (int64_t j = 0; j < nr; ++j) if (out_idx[j] >= 0) { ok.push_back(out_idx[j]); pos.push_back(j); }
+    std::vector<float> tmp(ok.size() * (size_t)h->dim);
+    if (!ok.empty() && (rc = vdb_fetch(h, ok.data(), (int64_t)ok.size(), tmp.data()))) return rc;
+    memset(out_rows, 0, (size_t)nr * h->dim * 4);
+    for (size_t j = 0; j < ok.size(); ++j) memcpy(out_rows + (size_t)pos[j] * h->dim, tmp.data() + j * (size_t)h->dim, (size_t)h->dim * 4);
+  }
   return VDB_OK;
+}
+}  // namespace
+
+int vdb_search(vdb_t* h, const float* queries_host, int b, int k, int kp, int64_t* out_idx, float* out_dist) {
+  if (!h) return VDB_ERR_ARG;
+  return search_host(h, queries_host, b, k, kp, out_idx, out_dist, nullptr);
+}
+
+int vdb_search_fetch(vdb_t* h, const float* queries_host, int b, int k, int kp, int64_t* out_idx, float* out_dist, float* out_rows) {
+  if (!h) return VDB_ERR_ARG;
+  if (b > 0 && !out_rows) return fail(h, VDB_ERR_ARG, "search_fetch: NULL rows buffer");
+  return search_host(h, queries_host, b, k, kp, out_idx, out_dist, out_rows);
 }
 
 int vdb_search_masked_dev(vdb_t* h, const float* queries_dev, int b, int k, int kp, const uint32_t* allow_dev,

@@ -113,6 +113,18 @@ class FlatIndex:
                                        idx.ctypes.data, dist.ctypes.data))
         return idx, dist
 
+    def search_fetch(self, queries, k: int, rerank_kprime: int = 0) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """search() plus the stored (normalised fp32) rows of the hits, [b, k, dim], in one round trip
+        (zero rows behind an index of -1): collection.query(include=["embeddings"]) as src/vectordb.py:259-264 makes it."""
+        q = _as_f32_2d(queries, self.dim, "queries")
+        b = q.shape[0]
+        idx = np.empty((b, k), np.int64)
+        dist = np.empty((b, k), np.float32)
+        rows = np.empty((b, k, self.dim), np.float32)
+        self._chk(self._lib.vdb_search_fetch(self._h, q.ctypes.data, b, int(k), int(rerank_kprime),
+                                             idx.ctypes.data, dist.ctypes.data, rows.ctypes.data))
+        return idx, dist, rows
+
     def search_masked(self, queries, k: int, allow, rerank_kprime: int = 0) -> Tuple[np.ndarray, np.ndarray]:
         """Exact top-k over the rows `allow` marks eligible (the `where=` pre-filter of
         collection.query, reference src/vectordb.py:230,259-264).  allow: boolean array,
