@@ -255,9 +255,10 @@ def main():
         raise SystemExit("bench.py needs a GPU (the engine has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+    if world > 1 or (args.force_collective and "TORCHELASTIC_RUN_ID" in os.environ):
+        dist.init_process_group("nccl", device_id=device)        # the launcher's store (env://)
     elif args.force_collective:
+        # (under the launcher a tcp:// init would look for the AGENT's store on that port and wait for ever)
         dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29631", rank=0, world_size=1, device_id=device)
 
     kp = args.kprime if args.dtype == "bf16" else 0
