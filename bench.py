@@ -126,6 +126,26 @@ def _chroma_note():
     return "chromadb importable: not timed by this script"
 
 
+def dist_rank0():
+    return int(os.environ.get("RANK", "0")) == 0
+
+
+def _library_gemm(m, n, k, iters=5):
+    import numpy as np
+    import torch
+    a = (torch.randn(m, k, device="cuda") / np.sqrt(k)).to(torch.bfloat16)
+    bt = (torch.randn(n, k, device="cuda") / np.sqrt(k)).to(torch.bfloat16)
+    c = torch.empty((m, n), dtype=torch.bfloat16, device="cuda")
+    for _ in range(2):
+        torch.matmul(a, bt.t(), out=c)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        torch.matmul(a, bt.t(), out=c)
+    torch.cuda.synchronize()
+    return 2.0 * m * n * k * iters / (time.perf_counter() - t0) / 1e12
+
+
 def measure(sh, args, b, steps, warmup, qspec, device, world, n_local):
     """Time `steps` steps of batch b (after `warmup` untimed ones) -> result block with its roofline."""
     import numpy as np
@@ -190,7 +210,7 @@ def measure(sh, args, b, steps, warmup, qspec, device, world, n_local):
     esz = 2 if args.dtype == "bf16" else 4
     path = sh.local.get_stat("last_path")            # 0 = GEMV scan, 4/5 = MFMA pass kernels, 6 = streaming MFMA kernel
     scan_ms = tstats["scan_ms_sum"] / max(tstats["n"], 1)
-    kernel = {0: "scan_topk_kernel", 4: "scan_mfma_ws_kernel<1> + sample passes", 5: "scan_mfma_wide_kernel<1> + sample passes",
+    kernel = {0: "scan_topk_kernel", 4: "scan_mfma_ws_kernel<1> + sample passes", 5: ("scan_mfma_wide_kernel<1>" if "mfma_shape16=0" in args.option else "scan_mfma_wide16_kernel<1>") + " + sample passes",
               6: "scan_stream_mfma_kernel<1> + sample passes"}.get(path, f"path {path}")
     if path in (4, 5):
         alg = 2.0 * b * n_local * dim
@@ -215,6 +235,11 @@ def measure(sh, args, b, steps, warmup, qspec, device, world, n_local):
         roof["frac_of_measured_peak"] = roof["achieved"] / roof["measured_peak"] if roof["measured_peak"] else None
     except RuntimeError:
         roof["measured_peak"] = None
+    if roof["bound"] == "mfma" and dist_rank0():
+        # the vendor library's bf16 GEMM (torch.matmul) on random operands on this box, outside the timed region: the
+        # search's own shape with the scores written out, and a square one (the chip is power-limited)
+        roof["library_gemm_tflops_random_operands"] = {"%dx262144x%d" % (b, dim): _library_gemm(b, 1 << 18, dim),
+                                                       "8192x8192x8192": _library_gemm(8192, 8192, 8192)}
     # HBM bytes per launch: only a rocprofv3 --pmc FETCH_SIZE pass can tell, and this invocation is not one
     # (profiles/r02_pmc_traffic.json holds the separate pass of this same command)
     roof["traffic"] = None
