@@ -1,0 +1,118 @@
+// mfma_tile_probe.hip — what a 256x256 block tile can reach when its operands are ALREADY in LDS (no staging, no
+// epilogue), on random bf16 data with every CU busy, as a function of the WAVE tile: 8 waves of 128x64 at two waves per
+// SIMD (the shipped wide kernel) against 4 waves of 128x128 at one wave per SIMD (512-register waves, one third fewer
+// fragment bytes read from LDS per flop).  The chip is power-limited on real operands, so the question is the wall-clock
+// FLOP/s each form holds, not its cycles.  Design input for DESIGN.md 4.2 / 8; not part of the library.
+//
+//   hipcc --offload-arch=gfx950 -O3 -o mfma_tile_probe mfma_tile_probe.hip && ./mfma_tile_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+// LDS image of one K=64 stage: 256 rows x 128 B per operand, 16-byte chunk c of row r at r*8 + (c ^ ((r>>1)&7))
+__device__ __forceinline__ unsigned frag_off(int row, int chunk) { return (unsigned)((row * 8 + (chunk ^ ((row >> 1) & 7))) * 16); }
+
+template <int NW, int NWN, int WM, int WN, bool READ_LDS>
+__global__ __launch_bounds__(NW * 64) void probe(const unsigned char* __restrict__ rnd, float* __restrict__ out, int iters) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  unsigned char* sA = smem;
+  unsigned char* sB = smem + 32768;
+  for (int i = threadIdx.x; i < 4096; i += NW * 64)
+    *(uint4*)(smem + i * 16) = *(const uint4*)(rnd + ((size_t)(blockIdx.x & 7) * 65536 + (size_t)i * 16));
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = w / NWN, wn = w % NWN;
+  constexpr int MT = WM / 16, NT = WN / 16;
+  f32x4_t acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  bf16x8_t fa[2][MT], fb[2][NT];
+  auto load = [&](int buf, int s, int off) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) fa[buf][i] = *(const bf16x8_t*)(sA + off + frag_off(wm * WM + i * 16 + (lane & 15), 4 * s + (lane >> 4)));
+#pragma unroll
+    for (int j = 0; j < NT; ++j) fb[buf][j] = *(const bf16x8_t*)(sB + off + frag_off(wn * WN + j * 16 + (lane & 15), 4 * s + (lane >> 4)));
+  };
+  load(0, 0, 0);
+#pragma unroll 1
+  for (int it = 0; it < iters; ++it) {
+    int off = 0;
+    asm volatile("" : "+v"(off));          // keeps hipcc from hoisting the (loop-invariant) fragment reads
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      if (READ_LDS) load(s ^ 1, s ^ 1, off);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[READ_LDS ? s : 0][i], fb[READ_LDS ? s : 0][j], acc[i][j], 0, 0, 0);
+    }
+  }
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+  out[(size_t)blockIdx.x * (NW * 64) + threadIdx.x] = t;
+}
+
+template <int NW, int NWN, int WM, int WN, bool READ_LDS>
+static void run(const char* name, const unsigned char* rnd, float* out, int blocks, int iters) {
+  auto k = probe<NW, NWN, WM, WN, READ_LDS>;
+  CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 96 << 10));   // 96 KiB: one block per CU
+  hipFuncAttributes fa;
+  CHECK(hipFuncGetAttributes(&fa, (const void*)k));
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  k<<<blocks, NW * 64, 96 << 10>>>(rnd, out, iters / 8);
+  CHECK(hipDeviceSynchronize());
+  float best = 1e30f, sum = 0.f;
+  const int reps = 5;
+  for (int r = 0; r < reps; ++r) {
+    CHECK(hipEventRecord(e0));
+    k<<<blocks, NW * 64, 96 << 10>>>(rnd, out, iters);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+    best = ms < best ? ms : best; sum += ms;
+  }
+  const double flop = (double)blocks * iters * 256.0 * 256.0 * 64.0 * 2.0;
+  printf("%-58s regs %3d spill %4zu B : mean %7.3f ms  %6.1f TFLOP/s  (best %6.1f)\n", name, fa.numRegs, (size_t)fa.localSizeBytes,
+         sum / reps, flop / (sum / reps * 1e-3) / 1e12, flop / (best * 1e-3) / 1e12);
+  fflush(stdout);
+}
+
+int main(int argc, char** argv) {
+  const int blocks = argc > 1 ? atoi(argv[1]) : 256;
+  const int iters = argc > 2 ? atoi(argv[2]) : 16384;
+  std::vector<uint16_t> h(8 * 32768);
+  uint64_t s = 0x9E3779B97F4A7C15ull;
+  for (auto& v : h) {                       // random bf16 of unit-vector size: +-(0.004 .. 0.07)
+    s = s * 6364136223846793005ull + 1442695040888963407ull;
+    const float f = (float)((s >> 33) % 2000 - 1000) / 1000.0f * 0.07f;
+    uint32_t u; memcpy(&u, &f, 4);
+    v = (uint16_t)((u + 0x7FFF + ((u >> 16) & 1)) >> 16);
+  }
+  unsigned char* rnd; float* out;
+  CHECK(hipMalloc(&rnd, h.size() * 2));
+  CHECK(hipMemcpy(rnd, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+  CHECK(hipMalloc(&out, (size_t)blocks * 512 * 4));
+  printf("# %d blocks x %d K-steps of a 256x256x64 block tile, v_mfma_f32_16x16x32_bf16, operands resident in LDS, random data\n", blocks, iters);
+  run<8, 4, 128, 64, true>("8 waves 2x4 of 128x64  (2 waves/SIMD, 24 reads / 64 MFMA)", rnd, out, blocks, iters);
+  run<8, 2, 64, 128, true>("8 waves 4x2 of 64x128  (2 waves/SIMD, 24 reads / 64 MFMA)", rnd, out, blocks, iters);
+  run<4, 2, 128, 128, true>("4 waves 2x2 of 128x128 (1 wave/SIMD,  32 reads / 128 MFMA)", rnd, out, blocks, iters);
+  run<8, 4, 128, 64, false>("8 waves 2x4 of 128x64, fragments read once (no LDS traffic)", rnd, out, blocks, iters);
+  run<4, 2, 128, 128, false>("4 waves 2x2 of 128x128, fragments read once (no LDS traffic)", rnd, out, blocks, iters);
+  run<8, 4, 128, 64, true>("8 waves 2x4 of 128x64  again (drift check)", rnd, out, blocks, iters);
+  return 0;
+}

@@ -1,12 +1,12 @@
 // k_mfma.hip — the batched bf16 path: Q.D^T on MFMA with the threshold/append protocol of scan_mfma3.h.
-// Host orchestration of one batched search (all buffers are the caller's) + the kernels' instantiations.
+// Host orchestration of one batched search (all buffers are the caller's) + the selection and fallback kernels; the pass
+// kernels instantiate in their own translation units behind mfma_pass.h.
 #include <algorithm>
 #include <cmath>
 #include "launch.h"
-#include "scan_mfma4.h"
-#include "scan_mfma5.h"
-#include "scan_mfma6.h"
-#include "scan_stream.h"
+#include "mfma_pass.h"
+#define VDB_MFMA_HOST_TU
+#include "scan_mfma3.h"
 
 namespace vdbk {
 namespace {
@@ -39,11 +39,11 @@ MfPlan mfma_plan(int b, int n_rows, int n_cu, int variant_opt) {
   (void)n_rows;
   MfPlan p;
   p.n_qt_fb = (b + kMfBN - 1) / kMfBN;
-  const int pad_wide = ((b + kM5BN - 1) / kM5BN) * kM5BN;
+  const int pad_wide = ((b + kM5BNC - 1) / kM5BNC) * kM5BNC;
   const bool wide = variant_opt >= 5 && 2 * pad_wide <= 3 * p.n_qt_fb * kMfBN;
-  const bool stream = variant_opt >= 6 && b <= kStMaxB;
+  const bool stream = variant_opt >= 6 && b <= kStMaxBC;
   p.variant = stream ? 6 : wide ? 5 : 4;
-  p.n_qt = stream ? 1 : wide ? pad_wide / kM5BN : p.n_qt_fb;
+  p.n_qt = stream ? 1 : wide ? pad_wide / kM5BNC : p.n_qt_fb;
   p.b_pad = std::max(wide ? pad_wide : p.n_qt_fb * kMfBN, p.n_qt_fb * kMfBN);   // >= the fallback's 128-wide tiles either way
   const long long n_tiles = ((long long)n_rows + kMfBM - 1) / kMfBM;
   p.fb_splits = mf_grid(n_cu, p.n_qt_fb, n_tiles, 64).n_splits;                   // fallback grid (<= 64 partial lists per query)
@@ -52,18 +52,10 @@ MfPlan mfma_plan(int b, int n_rows, int n_cu, int variant_opt) {
 
 hipError_t mfma_prepare_device() {
   MF_TRY(hipFuncSetAttribute((const void*)scan_mfma_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_smem_bytes()));
-  MF_TRY(hipFuncSetAttribute((const void*)scan_mfma_ws_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_smem_bytes()));
-  MF_TRY(hipFuncSetAttribute((const void*)scan_mfma_ws_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_smem_bytes()));
-  MF_TRY(hipFuncSetAttribute((const void*)scan_mfma_wide_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m5_smem_bytes()));
-  MF_TRY(hipFuncSetAttribute((const void*)scan_mfma_wide_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m5_smem_bytes()));
-  MF_TRY(hipFuncSetAttribute((const void*)scan_mfma_wide_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m5_smem_bytes()));
-  MF_TRY(hipFuncSetAttribute((const void*)scan_mfma_wide_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m5_smem_bytes()));
-  MF_TRY(hipFuncSetAttribute((const void*)scan_mfma_wide_kernel<1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m5_smem_bytes()));
-  MF_TRY(hipFuncSetAttribute((const void*)scan_mfma_wide16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m5_smem_bytes()));
-  MF_TRY(hipFuncSetAttribute((const void*)scan_mfma_wide16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m5_smem_bytes()));
-  MF_TRY(hipFuncSetAttribute((const void*)scan_mfma_wide16_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m5_smem_bytes()));
-  MF_TRY(hipFuncSetAttribute((const void*)scan_mfma_wide16_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m5_smem_bytes()));
-  MF_TRY(stream_prepare_device());
+  MF_TRY(ws_prepare_device());
+  MF_TRY(wide_prepare_device());
+  MF_TRY(wide16_prepare_device());
+  MF_TRY(stream_prepare());
   return hipSuccess;
 }
 
@@ -88,45 +80,16 @@ hipError_t mfma_search_launch(const MfSearchArgs& a, int* skipped_tiles) {
 
   // one pass of whichever kernel serves this batch; mode 0 = dense sample, 1 = append
   auto launch_pass = [&](int mode, long long pass_tiles, int stride, int skip_n) -> hipError_t {
-    if (variant == 6) {
-      stream_launch_pass(mode, rows, n_rows, qb16, b, (int)pass_tiles, stride, skip_n, self0, mode ? (const float*)thr : nullptr, dense,
-                         cand_cnt, cand_s, cand_i, cap, a.n_cu, a.stream_nt, a.stream_blocks_per_cu, a.stream_lds, st);
-      return hipGetLastError();
-    }
     const MfGrid g = mf_grid(a.n_cu, n_qt, pass_tiles, 1 << 30);
-    if (variant == 5 && a.shape16) {
-      if (mode == 0)
-        hipLaunchKernelGGL((scan_mfma_wide16_kernel<0>), dim3(n_qt * g.n_splits), dim3(kM5Threads), m5_smem_bytes(), st, rows, n_rows, qb16, b,
-                           n_qt, g.n_splits, g.tiles_per_split, (int)pass_tiles, stride, self0, g.xcd_map, (const float*)nullptr, dense,
-                           (int*)nullptr, (float*)nullptr, (int*)nullptr, 0, 0, 0);
-      else {
-        auto kern = (a.ablate & 1) ? scan_mfma_wide16_kernel<1, 1> : (a.ablate & 2) ? scan_mfma_wide16_kernel<1, 2> : scan_mfma_wide16_kernel<1, 0>;
-        hipLaunchKernelGGL(kern, dim3(n_qt * g.n_splits), dim3(kM5Threads), m5_smem_bytes(), st, rows, n_rows, qb16, b,
-                           n_qt, g.n_splits, g.tiles_per_split, (int)pass_tiles, stride, self0, g.xcd_map, (const float*)thr, dense,
-                           cand_cnt, cand_s, cand_i, cap, a.ablate, skip_n);
-      }
-    } else if (variant == 5) {
-      if (mode == 0)
-        hipLaunchKernelGGL((scan_mfma_wide_kernel<0>), dim3(n_qt * g.n_splits), dim3(kM5Threads), m5_smem_bytes(), st, rows, n_rows, qb16, b,
-                           n_qt, g.n_splits, g.tiles_per_split, (int)pass_tiles, stride, self0, g.xcd_map, (const float*)nullptr, dense,
-                           (int*)nullptr, (float*)nullptr, (int*)nullptr, 0, 0, 0);
-      else {
-        auto kern = (a.ablate & 8) ? scan_mfma_wide_kernel<1, 3> : (a.ablate & 1) ? scan_mfma_wide_kernel<1, 1> : (a.ablate & 2) ? scan_mfma_wide_kernel<1, 2> : scan_mfma_wide_kernel<1, 0>;
-        hipLaunchKernelGGL(kern, dim3(n_qt * g.n_splits), dim3(kM5Threads), m5_smem_bytes(), st, rows, n_rows, qb16, b,
-                           n_qt, g.n_splits, g.tiles_per_split, (int)pass_tiles, stride, self0, g.xcd_map, (const float*)thr, dense,
-                           cand_cnt, cand_s, cand_i, cap, a.ablate, skip_n);
-      }
-    } else {
-      if (mode == 0)
-        hipLaunchKernelGGL((scan_mfma_ws_kernel<0>), dim3(n_qt * g.n_splits), dim3(kWsThreads), ws_smem_bytes(), st, rows, n_rows, qb16, b,
-                           n_qt, g.n_splits, g.tiles_per_split, (int)pass_tiles, stride, self0, g.xcd_map, (const float*)nullptr, dense,
-                           (int*)nullptr, (float*)nullptr, (int*)nullptr, 0, ovf, 0, 0);
-      else
-        hipLaunchKernelGGL((scan_mfma_ws_kernel<1>), dim3(n_qt * g.n_splits), dim3(kWsThreads), ws_smem_bytes(), st, rows, n_rows, qb16, b,
-                           n_qt, g.n_splits, g.tiles_per_split, (int)pass_tiles, stride, self0, g.xcd_map, (const float*)thr, dense,
-                           cand_cnt, cand_s, cand_i, cap, ovf, a.ablate, skip_n);
-    }
-    return hipGetLastError();
+    MfPassArgs p;
+    p.mode = mode; p.rows = rows; p.n_rows = n_rows; p.qb16 = qb16; p.b = b;
+    p.n_qt = n_qt; p.n_splits = g.n_splits; p.tiles_per_split = g.tiles_per_split; p.xcd_map = g.xcd_map;
+    p.pass_tiles = (int)pass_tiles; p.stride = stride; p.skip_n = skip_n; p.self0 = self0;
+    p.thr = thr; p.dense = dense; p.cand_cnt = cand_cnt; p.cand_s = cand_s; p.cand_i = cand_i; p.cap = cap;
+    p.ovf = ovf; p.ablate = a.ablate; p.st = st;
+    if (variant == 6) return stream_pass(p, a.n_cu, a.stream_nt, a.stream_blocks_per_cu, a.stream_lds);
+    if (variant == 5) return a.shape16 ? wide16_launch_pass(p) : wide_launch_pass(p);
+    return ws_launch_pass(p);
   };
 
   // pass 0: dense scores of a strided 16-tile sample -> t0 = a lower bound of the k'-th best per query

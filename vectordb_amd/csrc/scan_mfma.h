@@ -55,6 +55,7 @@ __host__ __device__ constexpr size_t mf_smem_bytes() {
   return (size_t)kMfNumStages * kMfStage + (size_t)kMfQueueCap * 12 + 64 + (size_t)kMfBN * 4;
 }
 
+#ifdef VDB_MFMA_HOST_TU   // kernels of the orchestrating TU (k_mfma.hip) only: every pass-kernel TU includes this header
 // fp32 normalised queries [b][768] -> bf16 [b_pad][768] (rows >= b zero)
 __global__ void queries_to_bf16_kernel(const float* __restrict__ qn, int b, int b_pad, uint16_t* __restrict__ out) {
   const long long total = (long long)b_pad * kMfDim;
@@ -66,6 +67,7 @@ __global__ void queries_to_bf16_kernel(const float* __restrict__ qn, int b, int 
     out[i] = (uint16_t)u;
   }
 }
+#endif
 
 // Which corpus tile is pass-local tile i?
 //   skip_n == 0 : i * stride — a strided sample (stride > 1) or every tile (stride 1).
@@ -151,6 +153,7 @@ __device__ __forceinline__ void mf_issue_piece(const MfSrc& src, const unsigned 
   }
 }
 
+#ifdef VDB_MFMA_HOST_TU   // kernels of the orchestrating TU (k_mfma.hip) only: every pass-kernel TU includes this header
 // insert (cs, ci) into the register list of local query j (compile-time after the switch)
 #define VDB_MF_INSERT_CASE(j)                                              \
   case j: {                                                                \
@@ -363,6 +366,7 @@ __global__ __launch_bounds__(kMfThreads) void scan_mfma_topk_kernel(const unsign
   }
 }
 #undef VDB_MF_INSERT_CASE
+#endif
 
 inline bool mfma_path_supported(int kk) { return kk <= kMfMaxKK; }
 

@@ -29,6 +29,7 @@ namespace vdbk {
 constexpr int kMf3DenseTiles = 16;                     // dense sample: 16 tiles = 4096 rows
 constexpr int kMf3DenseLd = kMf3DenseTiles * kMfBM;
 
+#ifdef VDB_MFMA_HOST_TU   // kernels of the orchestrating TU (k_mfma.hip) only: every pass-kernel TU includes this header
 // Per query: the k'-th best of its candidates -> thr_out[q]; optionally the sorted top-k'
 // list -> list_*[q][kk].  Candidates: dense scores (cand_i == nullptr, index = position) or
 // an append buffer with cand_cnt[q] entries (capacity cap; more -> *overflow = 1), optionally merged with a
@@ -104,5 +105,6 @@ __global__ __launch_bounds__(64) void dense_lower_bound_kernel(const float* __re
   const float t = __shfl(v, kk - 1);
   if (lane == 0) thr_out[q] = t;
 }
+#endif
 
 }  // namespace vdbk
