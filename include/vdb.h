@@ -128,7 +128,13 @@ int vdb_count(vdb_t* h, int64_t* n);
  * Precision: an fp32 store, and a bf16 store with a rerank, return fp32 cosines of the stored fp32 rows whatever the
  * batch size.  A bf16 store searched WITHOUT a rerank returns the exact top-k of <fp32 query, bf16 row> scores; it
  * always runs on the GEMV scan (the batched MFMA kernels round the queries to bf16 as well, which only a rerank
- * repairs), so its result does not depend on the batch size either. */
+ * repairs), so its result does not depend on the batch size either.
+ * Limit of the rerank: the k' candidates are chosen by bf16 scores (resolution 2^-9 relative), so a true top-k row can
+ * be missed when MORE than k' rows lie within that resolution of the k-th best — clusters of near-duplicates larger
+ * than k', or thousands of unit vectors in two or three dimensions.  The returned rows, their fp32 distances and their
+ * order are still exact for what is returned, and the k-th distance is within bf16 resolution of the true one; on
+ * embedding-like data k' = 4k gives recall 1.0 at 10M rows (tests/test_gpu_fullsize.py).  Where that is not enough: a
+ * larger k' (up to 1024) or an fp32 store. */
 int vdb_search(vdb_t* h, const float* queries_host, int b, int k, int rerank_kprime,
                int64_t* out_idx_host, float* out_dist_host);
 

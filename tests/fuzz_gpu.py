@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Randomised soak of the BATCHED path (bf16 768-d store + fp32 rerank; --family gemv: the scan path at any shape) against the oracle — not collected by pytest
+(the GPU suite holds the seeded cases this found or could have found); run by hand on a GPU box:
+
+    python3 tests/fuzz_gpu.py [--cases 60] [--seed 1] [--budget-s 600] [--family batched|gemv|both]
+
+Every case draws a store size that is ragged against the 16-row wave tiles / 256-row protocol tiles / the dense sample,
+a data kind (clustered, isotropic, heavy duplicates = ties, queries that ARE rows), a batch size around the kernel
+families' borders, k / k', and a random setting of the engine's path options (kernel family, MFMA shape, LDS ring,
+skip-sample, a tiny append cap that forces the overflow fallback, sharding over repeated device ids), then checks
+ids, distances, order and padding with tests/util.check_topk (tie-tolerant, 1e-5)."""
+import argparse
+import os
+import sys
+import time
+import traceback
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from oracle import oracle  # noqa: E402
+from util import check_topk  # noqa: E402
+from vectordb_amd import FlatIndex, SynthSpec  # noqa: E402
+
+
+def make_rows(rng, kind, n, dim):
+    if kind == "clustered":
+        spec = SynthSpec(seed=int(rng.integers(1, 1 << 30)), kind=1, n_clusters=max(1, int(np.sqrt(n))), noise=0.3)
+        return oracle.synth_rows(0, n, dim, spec)
+    if kind == "isotropic":
+        return rng.standard_normal((n, dim)).astype(np.float32)
+    if kind == "duplicates":                       # 37 distinct directions, each repeated ~n/37 times, shuffled
+        base = rng.standard_normal((37, dim)).astype(np.float32)
+        return base[rng.integers(0, 37, n)]
+    if kind == "near_duplicates":                  # the same, one bf16 ulp of noise apart: candidate order is fragile
+        base = rng.standard_normal((37, dim)).astype(np.float32)
+        return base[rng.integers(0, 37, n)] + 1e-3 * rng.standard_normal((n, dim)).astype(np.float32)
+    raise ValueError(kind)
+
+
+def one_case(rng, case):
+    dim = 768
+    n = int(rng.choice([4096, 4097, 4111, 5000, 8191, 8192, 12345, 20011, 33003, 50001]))
+    kind = str(rng.choice(["clustered", "isotropic", "duplicates", "near_duplicates"]))
+    b = int(rng.choice([2, 3, 5, 16, 17, 48, 63, 64, 65, 100, 128, 129, 255, 256, 257, 300, 513]))
+    k = int(rng.choice([1, 2, 5, 10, 16]))
+    kp = int(rng.choice([max(4 * k, 16), 64, 40 if k <= 10 else 64]))
+    opts = {
+        "mfma_cost_model": int(rng.integers(0, 2)),
+        "mfma_variant": int(rng.choice([4, 5, 6, 6])),
+        "mfma_shape16": int(rng.integers(0, 2)),
+        "mfma_skip_sample": int(rng.integers(0, 2)),
+        "stream_lds_ring": int(rng.integers(0, 3)),
+        "stream_nt_loads": int(rng.integers(0, 2)),
+        "mfma_append_cap": int(rng.choice([256, 1024, 16384, 16384])),
+        "mfma_split_x1000": int(rng.choice([250, 500, 650])),
+    }
+    g = int(rng.choice([0, 0, 2, 3]))              # 0 = plain handle, else shards over repeated device 0
+    rows = make_rows(rng, kind, n, dim)
+    if str(rng.choice(["planted", "rows", "noise"])) == "rows":
+        q = rows[rng.integers(0, n, b)].copy()
+    else:
+        q = rows[rng.integers(0, n, b)] + 0.3 * rng.standard_normal((b, dim)).astype(np.float32)
+    what = f"case {case}: n={n} {kind} b={b} k={k} kp={kp} g={g} {opts}"
+    rows_n = oracle.normalize_rows(rows)
+    ix = FlatIndex(dim, "bf16", True, devices=[0] * g) if g else FlatIndex(dim, "bf16", True)
+    try:
+        for name, v in opts.items():
+            ix.set_option(name, v)
+        if g:
+            ix.reserve(n)
+        cut = int(rng.integers(1, n))
+        ix.add(rows[:cut]); ix.add(rows[cut:])
+        idx, dist = ix.search(q, k, kp)
+        path = ix.get_stat("last_path")
+        ovf = ix.get_stat("mfma_last_overflow") if not g else -1
+        r_idx, r_dist, r_sc = oracle.exact_topk(rows_n, q, k)
+        if kind == "near_duplicates":
+            # hundreds of rows within 1e-4 of each other in fp32 and indistinguishable in bf16: WHICH k' of them the bf16
+            # candidate pass keeps is arbitrary (the documented limit of bf16 + k' rerank, for the oracle's bf16 twin
+            # too), so only what must still hold is checked: exact distances of the returned rows, order, no repeats,
+            # and a k-th distance within bf16 resolution of the true one
+            qn = oracle.normalize_rows(q)
+            swaps = -1
+            for j in range(b):
+                got = idx[j]
+                assert len(set(got.tolist())) == k and got.min() >= 0, what + f" q{j}: ids {got}"
+                true_d = 1.0 - (rows_n[got].astype(np.float64) @ qn[j].astype(np.float64))
+                assert np.all(np.abs(true_d - dist[j]) <= 2e-6), what + f" q{j}: distance != 1-cos of the returned row"
+                assert np.all(np.diff(dist[j].astype(np.float64)) >= -2e-6), what + f" q{j}: not ascending"
+                assert dist[j, -1] <= r_dist[j, -1] + 8e-3, what + f" q{j}: k-th distance beyond bf16 resolution of the true one"
+        else:
+            swaps = check_topk(idx, dist, r_idx, r_dist, r_sc, rows_n, oracle.normalize_rows(q), what=what)
+        # the same batch one query at a time (GEMV scan) returns the same rows wherever the answer is not a tie
+        j = int(rng.integers(0, b))
+        i1, d1 = ix.search(q[j:j + 1], k, kp)
+        if not np.array_equal(i1[0], idx[j]):
+            assert np.allclose(d1[0], dist[j], atol=2e-5), what + f" (query {j}: batch and single answers differ beyond a tie)"
+        return f"ok   path={path} ovf={ovf} swaps={swaps}  {what}"
+    finally:
+        ix.close()
+
+
+def gemv_case(rng, case):
+    """The scan path: any dim, f32 or bf16 (with and without rerank), k up to 1024, masks, the entry point that allocates
+    nothing, hits with their rows, a row offset."""
+    import torch
+    dim = int(rng.choice([1, 2, 7, 8, 33, 64, 100, 384, 385, 768, 769, 1024, 1100]))
+    n = int(rng.choice([1, 5, 63, 64, 65, 257, 1000, 4095, 4097, 9999, 30011]))
+    b = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 63, 64, 65, 150]))
+    k = int(rng.choice([1, 3, 10, 64, 65, 200, 1024]))
+    dtype = str(rng.choice(["f32", "bf16"]))
+    kp = 0
+    if dtype == "bf16" and rng.integers(0, 2):
+        kp = int(min(1024, max(k, rng.choice([k, 4 * k, 64]))))
+    off = int(rng.choice([0, 0, 1 << 33]))
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    if n > 5:
+        rows[5] = rows[2]
+    q = rng.standard_normal((b, dim)).astype(np.float32)
+    what = f"gemv case {case}: n={n} dim={dim} b={b} k={k} {dtype} kp={kp} off={off}"
+    rows_n = oracle.normalize_rows(rows)
+    src = oracle.round_bf16(rows_n) if (dtype == "bf16" and kp == 0) else rows_n
+    qn = oracle.normalize_rows(q)
+    ix = FlatIndex(dim, dtype, True)
+    try:
+        ix.set_option("mfma_cost_model", int(rng.integers(0, 2)))
+        ix.add(rows)
+        if off:
+            ix.set_row_offset(off)
+        kk = min(k, n)
+        r_idx, r_dist, r_sc = oracle.exact_topk(src, q, kk)
+        # bf16 candidates + k' rerank: recall is not guaranteed with k' < 4k, nor in a few dimensions (10k unit vectors in
+        # 2-D sit closer together than bf16 resolves: seed 11, case 90 returned the 2.5e-4 neighbour for the 4e-7 one)
+        strict = not (dtype == "bf16" and kp and (kp < 4 * k or dim < 33))
+        idx, dist, got_rows = ix.search_fetch(q, k, kp)
+        assert np.all(idx[:, kk:] == -1) and np.all(np.isinf(dist[:, kk:])), what
+        if strict:
+            check_topk(idx[:, :kk], dist[:, :kk], r_idx, r_dist, r_sc, src, qn, row_offset=off, what=what)
+        stored = ix.fetch((idx[:, :kk].reshape(-1) - off))
+        assert np.array_equal(got_rows[:, :kk].reshape(-1, dim), stored) and np.all(got_rows[:, kk:] == 0), what + " fetch"
+        i2, d2 = ix.search(q, k, kp)
+        assert np.array_equal(i2, idx) and np.array_equal(d2, dist), what + " search vs search_fetch"
+        if b <= 8 and (kp or k) <= 64 and dim <= 4096:
+            qd = torch.from_numpy(q).cuda()
+            oi = torch.empty((b, k), dtype=torch.int64, device="cuda"); od = torch.empty((b, k), dtype=torch.float32, device="cuda")
+            ix.search_device_noalloc(qd.data_ptr(), b, k, kp, oi.data_ptr(), od.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            same = np.array_equal(oi.cpu().numpy(), idx) and np.array_equal(od.cpu().numpy(), dist)   # (the batched path may break a tie differently)
+            assert same or not strict or np.allclose(od.cpu().numpy()[:, :kk], dist[:, :kk], atol=2e-5), what + " noalloc"
+        mask = rng.random(n) < 0.4
+        allowed = np.flatnonzero(mask)
+        mi, md = ix.search_masked(q, k, mask, kp)
+        km = min(k, allowed.size)
+        assert np.all(mi[:, km:] == -1) and np.all(np.isinf(md[:, km:])), what + " masked padding"
+        if km and strict:
+            m_idx, m_dist, m_sc = oracle.exact_topk(src[allowed], q, km)
+            check_topk(mi[:, :km], md[:, :km], allowed[m_idx], m_dist, m_sc, src, qn, row_offset=off, what=what + " masked")
+        return f"ok   path={ix.get_stat('last_path')}  {what}"
+    finally:
+        ix.close()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=60)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--budget-s", type=float, default=600.0)
+    ap.add_argument("--family", default="batched", choices=["batched", "gemv", "both"])
+    args = ap.parse_args()
+    rng = np.random.default_rng(args.seed)
+    t0 = time.time()
+    bad = 0
+    done = 0
+    for case in range(args.cases):
+        if time.time() - t0 > args.budget_s:
+            break
+        try:
+            fn = gemv_case if args.family == "gemv" or (args.family == "both" and case % 2) else one_case
+            print(fn(rng, case), flush=True)
+        except AssertionError as e:
+            bad += 1
+            print("FAIL", str(e)[:1500], flush=True)
+        except Exception:
+            bad += 1
+            print("ERROR", traceback.format_exc()[-1500:], flush=True)
+        done += 1
+    print(f"{done} cases, {bad} failed, {time.time() - t0:.0f} s", flush=True)
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -365,3 +365,40 @@ def test_search_fetch_returns_the_hits_rows_in_one_call(hip_lib, oracle_mod, cor
     i, d, r = tiny.search_fetch(rng.standard_normal((2, 64)).astype(np.float32), 5)
     assert np.all(i[:, 3:] == -1) and np.all(r[:, 3:] == 0) and np.all(np.abs(np.linalg.norm(r[:, :3], axis=2) - 1) < 1e-5)
     tiny.close()
+
+
+def test_near_duplicate_clusters_show_the_limit_of_bf16_candidates(hip_lib, oracle_mod):
+    """37 directions, ~220 rows each, 1e-3 of noise apart: in fp32 the rows of a cluster differ by ~1e-5 in score, in bf16
+    not at all, so WHICH k' of a cluster the candidate pass keeps is arbitrary (found by tests/fuzz_gpu.py; include/vdb.h
+    states the limit).  What must hold: returned rows carry their exact fp32 distances in order without repeats, the k-th
+    distance is within bf16 resolution of the true one — on every kernel family — and an fp32 store (or k' = the whole
+    cluster) returns the exact answer."""
+    rng = np.random.default_rng(99)
+    n, dim, b, k = 8191, 768, 65, 10
+    base = rng.standard_normal((37, dim)).astype(np.float32)
+    rows = base[rng.integers(0, 37, n)] + 1e-3 * rng.standard_normal((n, dim)).astype(np.float32)
+    q = rows[rng.integers(0, n, b)] + 0.3 * rng.standard_normal((b, dim)).astype(np.float32)
+    rows_n = oracle_mod.normalize_rows(rows)
+    qn = _qn(oracle_mod, q)
+    r_idx, r_dist, r_sc = oracle_mod.exact_topk(rows_n, q, k)
+    ix = FlatIndex(dim, "bf16", True)
+    ix.set_option("mfma_cost_model", 0)
+    ix.add(rows)
+    for nb, variant in ((b, 4), (b, 5), (33, 6), (1, 6)):          # 128-wide tile, wide tile, streaming kernel, GEMV scan
+        ix.set_option("mfma_variant", variant)
+        idx, dist = ix.search(q[:nb], k, 40)
+        for j in range(nb):
+            got = idx[j]
+            assert len(set(got.tolist())) == k and got.min() >= 0
+            true_d = 1.0 - rows_n[got].astype(np.float64) @ qn[j].astype(np.float64)
+            assert np.all(np.abs(true_d - dist[j]) <= 2e-6) and np.all(np.diff(dist[j].astype(np.float64)) >= -2e-6)
+            assert dist[j, -1] <= r_dist[j, -1] + 8e-3
+    ix.set_option("mfma_variant", 6)
+    idx, dist = ix.search(q, k, 1024)                               # k' larger than any cluster: exact again
+    check_topk(idx, dist, r_idx, r_dist, r_sc, rows_n, qn, what="near-duplicates k'=1024")
+    ix.close()
+    fx = FlatIndex(dim, "f32")
+    fx.add(rows)
+    idx, dist = fx.search(q, k)
+    check_topk(idx, dist, r_idx, r_dist, r_sc, rows_n, qn, what="near-duplicates f32 store")
+    fx.close()
