@@ -2,7 +2,7 @@
 """Randomised soak of the BATCHED path (bf16 768-d store + fp32 rerank; --family gemv: the scan path at any shape) against the oracle — not collected by pytest
 (the GPU suite holds the seeded cases this found or could have found); run by hand on a GPU box:
 
-    python3 tests/fuzz_gpu.py [--cases 60] [--seed 1] [--budget-s 600] [--family batched|gemv|both]
+    python3 tests/fuzz_gpu.py [--cases 60] [--seed 1] [--budget-s 600] [--family batched|gemv|both|state]
 
 Every case draws a store size that is ragged against the 16-row wave tiles / 256-row protocol tiles / the dense sample,
 a data kind (clustered, isotropic, heavy duplicates = ties, queries that ARE rows), a batch size around the kernel
@@ -163,12 +163,98 @@ def gemv_case(rng, case):
         ix.close()
 
 
+def _same_answer(a, b, what, tol=2e-5):
+    """Two engines' (idx, dist): distances agree, and ids agree wherever the neighbours are not tied."""
+    (ia, da), (ib, db) = a, b
+    assert ia.shape == ib.shape and da.shape == db.shape, what
+    fin = np.isfinite(db)
+    assert np.array_equal(np.isfinite(da), fin) and np.array_equal(ia[~fin], ib[~fin]), what + " padding"
+    assert np.allclose(da[fin], db[fin], atol=tol), what + f" distances {np.abs(da[fin] - db[fin]).max()}"
+    for q in range(ia.shape[0]):
+        bad = np.flatnonzero(ia[q] != ib[q])
+        for j in bad:                       # a differing id must sit in a run of (near-)equal distances
+            lo = max(0, j - 1); hi = min(ia.shape[1] - 1, j + 1)
+            assert abs(db[q, j] - db[q, lo]) <= tol or abs(db[q, hi] - db[q, j]) <= tol or j == ia.shape[1] - 1, what + f" q{q} rank {j}: {ia[q]} vs {ib[q]}"
+
+
+def state_case(rng, case):
+    """Model-based: one random sequence of calls (appends in ragged chunks, searches of every family, masked searches,
+    fetches, self-joins, save + reopen under another shard count) applied to the HIP handle and to the oracle's ABI
+    twin; every output is compared."""
+    import tempfile
+    olib = oracle.lib()
+    dim = int(rng.choice([768, 768, 64, 100]))
+    dtype = str(rng.choice(["bf16", "f32"])) if dim != 768 else "bf16"
+    g = int(rng.choice([0, 0, 2, 3]))
+    total = int(rng.choice([300, 5000, 9000, 20000]))
+    what0 = f"state case {case}: dim={dim} {dtype} g={g} total={total}"
+    hx = FlatIndex(dim, dtype, True, devices=[0] * g) if g else FlatIndex(dim, dtype, True)
+    ox = FlatIndex(dim, dtype, True, lib=olib, devices=[0] * g) if g else FlatIndex(dim, dtype, True, lib=olib)
+    log = []
+    try:
+        if g:
+            hx.reserve(total); ox.reserve(total)
+        hx.set_option("mfma_cost_model", int(rng.integers(0, 2)))
+        base = rng.standard_normal((61, dim)).astype(np.float32)
+        for step in range(int(rng.integers(6, 14))):
+            n = hx.count()
+            assert n == ox.count(), what0 + " count"
+            op = str(rng.choice(["add", "add", "search", "search", "masked", "fetch", "selfjoin", "reopen"]))
+            what = what0 + f" step {step} {op} n={n} after {log}"
+            if op == "add" or n == 0:
+                m = int(rng.choice([1, 7, 255, 256, 257, 1000, 4097]))
+                rows = base[rng.integers(0, 61, m)] + 0.4 * rng.standard_normal((m, dim)).astype(np.float32)
+                hx.add(rows); ox.add(rows)
+                log.append(f"add{m}")
+                continue
+            kp_ok = dtype == "bf16"
+            k = int(rng.choice([1, 5, 10, 40]))
+            kp = int(rng.choice([0, 4 * k if 4 * k <= 64 else 64])) if kp_ok else 0
+            if kp and kp < k:
+                kp = k
+            b = int(rng.choice([1, 2, 4, 9, 64, 65, 130, 300]))
+            q = base[rng.integers(0, 61, b)] + 0.4 * rng.standard_normal((b, dim)).astype(np.float32)
+            if op == "search":
+                _same_answer(hx.search(q, k, kp), ox.search(q, k, kp), what + f" b={b} k={k} kp={kp}")
+                log.append(f"s{b}")
+            elif op == "masked" and not g:
+                mask = rng.random(n) < float(rng.choice([0.02, 0.5, 1.0]))
+                _same_answer(hx.search_masked(q, k, mask, kp), ox.search_masked(q, k, mask, kp), what + f" b={b} k={k} kp={kp}")
+                log.append(f"m{b}")
+            elif op == "fetch":
+                idx = rng.integers(0, n, int(rng.integers(1, 50)))
+                a, r = hx.fetch(idx), ox.fetch(idx)
+                assert np.max(np.abs(a.view(np.int32).astype(np.int64) - r.view(np.int32).astype(np.int64))) <= 1, what   # <= 1 ulp
+                log.append("f")
+            elif op == "selfjoin" and not g and n >= 2:
+                q0 = int(rng.integers(0, n)); qn_ = int(rng.integers(1, min(200, n - q0) + 1))
+                ex = bool(rng.integers(0, 2))
+                _same_answer(hx.selfjoin(k, exclude_self=ex, rerank_kprime=kp, q_row0=q0, q_n=qn_),
+                             ox.selfjoin(k, exclude_self=ex, rerank_kprime=kp, q_row0=q0, q_n=qn_), what + f" q0={q0} qn={qn_} ex={ex} k={k} kp={kp}")
+                log.append("j")
+            elif op == "reopen":
+                g2 = int(rng.choice([0, 2, 3]))
+                with tempfile.TemporaryDirectory() as d:
+                    hx.save(d + "/h"); ox.save(d + "/o")
+                    assert open(d + "/h/vectors.vdb", "rb").read(32) == open(d + "/o/vectors.vdb", "rb").read(32), what + " header"
+                    hx.close(); ox.close()
+                    kw = dict(devices=[0] * g2) if g2 else {}
+                    hx = FlatIndex.load(d + "/h", dtype, True, **kw)
+                    ox = FlatIndex.load(d + "/h", dtype, True, lib=olib, **kw)      # the oracle reads the HIP engine's file
+                g = g2
+                hx.set_option("mfma_cost_model", int(rng.integers(0, 2)))
+                log.append(f"reopen{g2}")
+        return f"ok   {what0} ops={' '.join(log)}"
+    finally:
+        hx.close(); ox.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=60)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--budget-s", type=float, default=600.0)
-    ap.add_argument("--family", default="batched", choices=["batched", "gemv", "both"])
+    ap.add_argument("--family", default="batched", choices=["batched", "gemv", "both", "state"])
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     t0 = time.time()
@@ -178,7 +264,7 @@ def main():
         if time.time() - t0 > args.budget_s:
             break
         try:
-            fn = gemv_case if args.family == "gemv" or (args.family == "both" and case % 2) else one_case
+            fn = state_case if args.family == "state" else gemv_case if args.family == "gemv" or (args.family == "both" and case % 2) else one_case
             print(fn(rng, case), flush=True)
         except AssertionError as e:
             bad += 1
