@@ -69,7 +69,7 @@ typedef struct vdb_synth_spec {
 /* Replaces chromadb.PersistentClient(...).get_or_create_collection(name,
  * metadata={"hnsw:space":"cosine"}) as the owner of the vector segment
  * (src/vectordb.py:149,156-160).  dtype: storage of the scanned copy.
- * keep_f32_for_rerank: with VDB_BF16, also keep fp32 rows for the rerank. */
+ * keep_f32_for_rerank: with VDB_BF16, also keep fp32 rows for the rerank (6 instead of 2 bytes per element). */
 int vdb_create(vdb_t** out, int dim, int dtype, int keep_f32_for_rerank, int device_id);
 
 /* The same store ROW-SHARDED over the GPUs of one node, inside one process and one host thread (SURVEY.md 8b/8e;
@@ -121,10 +121,14 @@ int vdb_count(vdb_t* h, int64_t* n);
  * analysis/run_bidirectional_test.py:139-143;
  * analysis/generate_best_usda_matches.py:196-200) and the top-k selection
  * inside chroma-hnswlib.  queries: host, b x dim fp32 (not required to be
- * normalised).  rerank_kprime: 0 = no rerank; otherwise (bf16 store with fp32
- * copy) the scan keeps k' >= k candidates that are re-scored in fp32
- * (the GPU analogue of src/vectordb.py:282-314).  Outputs: b x k, padded with
- * idx -1 / dist +inf when fewer than k rows exist.
+ * normalised).  rerank_kprime: 0 = no rerank; otherwise (bf16 store) the scan
+ * keeps k' >= k candidates that are re-scored in fp32 against the fp32 copy
+ * (the GPU analogue of src/vectordb.py:282-314) — or, on a bf16 store created
+ * WITHOUT the fp32 copy (2 bytes per element: 100M x 768 rows fit one GPU),
+ * against the stored bf16 rows with the fp32 query: the answer is then that of
+ * rerank_kprime = 0 (the exact top-k of <fp32 query, bf16 row>), but batches may
+ * take the batched MFMA kernels instead of ceil(b/4) scan passes.  Outputs: b x k,
+ * padded with idx -1 / dist +inf when fewer than k rows exist.
  * Precision: an fp32 store, and a bf16 store with a rerank, return fp32 cosines of the stored fp32 rows whatever the
  * batch size.  A bf16 store searched WITHOUT a rerank returns the exact top-k of <fp32 query, bf16 row> scores; it
  * always runs on the GEMV scan (the batched MFMA kernels round the queries to bf16 as well, which only a rerank

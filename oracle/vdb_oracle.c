@@ -297,7 +297,7 @@ static int check_search_args(vdb_t* h, const void* q, int b, int k, int kp, cons
   if (b < 0 || (b > 0 && (!q || !oi || !od))) return fail(h, VDB_ERR_ARG, "search: NULL buffer");
   if (k < 1 || k > VDB_MAX_K) return fail(h, VDB_ERR_ARG, "search: k must be in [1,1024]");
   if (kp != 0 && (kp < k || kp > VDB_MAX_K)) return fail(h, VDB_ERR_ARG, "search: rerank_kprime must be 0 or in [k,1024]");
-  if (kp != 0 && !(h->dtype == VDB_BF16 && h->keep_f32)) return fail(h, VDB_ERR_STATE, "search: rerank needs a bf16 store created with keep_f32_for_rerank");
+  if (kp != 0 && h->dtype != VDB_BF16) return fail(h, VDB_ERR_STATE, "search: rerank_kprime needs a bf16 store");
   return VDB_OK;
 }
 
@@ -307,13 +307,19 @@ static void search_one(vdb_t* h, const float* qn, int k, int kp, int64_t exclude
   cand_t* L = (cand_t*)malloc(sizeof(cand_t) * (size_t)kk);
   int cnt = scan_one(h->dtype == VDB_BF16 ? NULL : h->rows, h->dtype == VDB_BF16 ? h->rows16 : NULL,
                      h->n, h->dim, qn, kk, exclude, allow, L);
-  if (kp) { /* exact fp32 re-score of the k' candidates, re-sort */
+  if (kp) { /* exact re-score of the k' candidates against the fp32 copy — or, on a store without one, against the stored
+               bf16 rows themselves (the scan's own scores again: the answer is the exact top-k of <fp32 q, bf16 row>) */
     cand_t* R = (cand_t*)malloc(sizeof(cand_t) * (size_t)kk);
     int rc = 0;
     for (int j = 0; j < cnt; ++j) {
-      const float* x = h->rows + L[j].i * h->dim;
       double acc = 0.0;
-      for (int c = 0; c < h->dim; ++c) acc += (double)qn[c] * (double)x[c];
+      if (h->keep_f32) {
+        const float* x = h->rows + L[j].i * h->dim;
+        for (int c = 0; c < h->dim; ++c) acc += (double)qn[c] * (double)x[c];
+      } else {
+        const uint16_t* x = h->rows16 + L[j].i * h->dim;
+        for (int c = 0; c < h->dim; ++c) acc += (double)qn[c] * (double)bf16_to_f32(x[c]);
+      }
       list_push(R, &rc, kk, acc, L[j].i);
     }
     memcpy(L, R, sizeof(cand_t) * (size_t)rc);

@@ -64,8 +64,12 @@ def one_case(rng, case):
     else:
         q = rows[rng.integers(0, n, b)] + 0.3 * rng.standard_normal((b, dim)).astype(np.float32)
     what = f"case {case}: n={n} {kind} b={b} k={k} kp={kp} g={g} {opts}"
+    keep = bool(rng.integers(0, 4))                # one store in four has no fp32 copy: candidates re-scored against the bf16 rows
+    what += f" keep_f32={int(keep)}"
     rows_n = oracle.normalize_rows(rows)
-    ix = FlatIndex(dim, "bf16", True, devices=[0] * g) if g else FlatIndex(dim, "bf16", True)
+    if not keep:
+        rows_n = oracle.round_bf16(rows_n)         # what such a store scores against
+    ix = FlatIndex(dim, "bf16", keep, devices=[0] * g) if g else FlatIndex(dim, "bf16", keep)
     try:
         for name, v in opts.items():
             ix.set_option(name, v)

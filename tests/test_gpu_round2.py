@@ -402,3 +402,37 @@ def test_near_duplicate_clusters_show_the_limit_of_bf16_candidates(hip_lib, orac
     idx, dist = fx.search(q, k)
     check_topk(idx, dist, r_idx, r_dist, r_sc, rows_n, qn, what="near-duplicates f32 store")
     fx.close()
+
+
+def test_batched_search_on_a_store_without_the_fp32_copy(hip_lib, oracle_mod, corpus33k):
+    """2 bytes per element (no fp32 copy): rerank_kprime re-scores the candidates against the stored bf16 rows with the
+    fp32 query, so every kernel family returns the scan's own answer — the exact top-k of <fp32 query, bf16 row> —
+    and batches no longer cost ceil(b/4) corpus passes."""
+    n, dim, spec, rows, _ = corpus33k
+    qspec = SynthSpec(seed=78, kind=2, noise=0.5, base_kind=1, base_seed=4321, base_n=n, base_n_clusters=181, base_noise=0.3)
+    queries = oracle_mod.synth_rows(0, 300, dim, qspec)
+    src = oracle_mod.round_bf16(rows)
+    qn = _qn(oracle_mod, queries)
+    r_idx, r_dist, r_sc = oracle_mod.exact_topk(src, queries, 10)
+    ix = FlatIndex(dim, "bf16", False)
+    ix.set_option("mfma_cost_model", 0)
+    ix.add_synth(0, n, spec)
+    i0, d0 = ix.search(queries, 10, 0)                       # the scan: 4 queries per corpus pass
+    assert ix.get_stat("last_path") == 0
+    check_topk(i0, d0, r_idx, r_dist, r_sc, src, qn, what="bf16-only scan")
+    for b, variant, path in ((300, 5, 5), (129, 4, 4), (64, 6, 6), (3, 6, 6), (1, 6, 0)):
+        ix.set_option("mfma_variant", variant)
+        idx, dist = ix.search(queries[:b], 10, 40)
+        assert ix.get_stat("last_path") == path and ix.get_stat("mfma_last_overflow") == 0
+        check_topk(idx, dist, r_idx[:b], r_dist[:b], r_sc[:b], src, qn[:b], what=f"bf16-only batched b={b} variant {variant}")
+        assert np.allclose(dist, d0[:b], atol=1e-6)
+    sj_i, sj_d = ix.selfjoin(5, exclude_self=True, rerank_kprime=40, q_row0=100, q_n=70)
+    assert not np.any(sj_i == (100 + np.arange(70))[:, None]) and np.all(np.diff(sj_d, axis=1) >= 0)
+    ix.close()
+    sh = FlatIndex(dim, "bf16", False, devices=[0, 0, 0])
+    sh.set_option("mfma_cost_model", 0)
+    sh.reserve(n)
+    sh.add_synth(0, n, spec)
+    idx, dist = sh.search(queries[:64], 10, 40)
+    check_topk(idx, dist, r_idx[:64], r_dist[:64], r_sc[:64], src, qn[:64], what="bf16-only sharded batched")
+    sh.close()

@@ -147,6 +147,30 @@ def test_search_fetch_on_the_oracle_twin_and_through_the_collection(oracle_lib, 
         assert np.allclose(res["embeddings"][j][0], rows[src] / np.linalg.norm(rows[src]), atol=1e-6)
 
 
+def test_rerank_on_a_store_without_the_fp32_copy_on_the_oracle_twin(oracle_lib, oracle_mod):
+    """A bf16 store created WITHOUT the fp32 copy accepts rerank_kprime: the k' candidates are re-scored against the
+    stored bf16 rows, so the answer is rerank_kprime = 0's (the exact top-k of <fp32 query, bf16 row>); an fp32 store
+    still refuses a rerank."""
+    rng = np.random.default_rng(6)
+    rows = rng.standard_normal((300, 48)).astype(np.float32)
+    q = rows[[5, 250]] + 0.05 * rng.standard_normal((2, 48)).astype(np.float32)
+    ix = FlatIndex(48, "bf16", False, lib=oracle_lib)
+    ix.add(rows)
+    i0, d0 = ix.search(q, 10, 0)
+    i1, d1 = ix.search(q, 10, 40)
+    assert np.array_equal(i0, i1) and np.allclose(d0, d1, atol=1e-7)
+    src = oracle_mod.round_bf16(oracle_mod.normalize_rows(rows))
+    r_idx, r_dist, _ = oracle_mod.exact_topk(src, q, 10)
+    assert np.array_equal(i1, r_idx) and np.allclose(d1, r_dist, atol=1e-6)
+    ix.close()
+    fx = FlatIndex(48, "f32", lib=oracle_lib)
+    fx.add(rows)
+    with pytest.raises(VdbError) as e:
+        fx.search(q, 10, 40)
+    assert e.value.code == -5
+    fx.close()
+
+
 def test_batched_best_match_maps_an_empty_answer_to_none(oracle_lib):
     """A product whose embedding is not finite gets no row back from the engine (idx -1 / +inf): it must read
     (None, -1.0) like the reference's loop (generate_best_usda_matches.py:116-143), not the last USDA code."""

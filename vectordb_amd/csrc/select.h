@@ -135,9 +135,19 @@ __global__ __launch_bounds__(256) void finalize_kernel(const float* __restrict__
   rank_and_write(ls, li, kk, k, row_offset, out_idx + (size_t)q * k, out_dist + (size_t)q * k);
 }
 
+// four consecutive elements j*4 .. j*4+3 of stored row `id`: from the fp32 copy, or (a store without one) from the bf16 rows
+__device__ __forceinline__ f32x4 stored_row4(const float* __restrict__ rows_f32, const uint16_t* __restrict__ rows_b16, int id, int ld, int j) {
+  if (rows_f32) return reinterpret_cast<const f32x4*>(rows_f32 + (size_t)id * ld)[j];
+  const uint2 u = reinterpret_cast<const uint2*>(rows_b16 + (size_t)id * ld)[j];
+  f32x4 r;
+  r.x = __uint_as_float(u.x << 16); r.y = __uint_as_float(u.x & 0xffff0000u);
+  r.z = __uint_as_float(u.y << 16); r.w = __uint_as_float(u.y & 0xffff0000u);
+  return r;
+}
+
 // fp32 rerank: exact fp32 dot of the query with each of the kk candidate rows
-// (fp32 copy of the store), then final ranking.  One block per query.
-__global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ rows_f32, int ld,
+// (fp32 copy of the store; rows_f32 == nullptr: the stored bf16 rows), then final ranking.  One block per query.
+__global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ rows_f32, const uint16_t* __restrict__ rows_b16, int ld,
                                                      const float* __restrict__ qn, const int* __restrict__ m_i,
                                                      int kk, int k, long long row_offset,
                                                      long long* __restrict__ out_idx,
@@ -154,10 +164,9 @@ __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ r
     const int id = m_i[(size_t)q * kk + c];
     float tot = -INFINITY;
     if (id != kIdxSentinel) {  // wave-uniform
-      const f32x4* rv = reinterpret_cast<const f32x4*>(rows_f32 + (size_t)id * ld);
       float acc = 0.f;
       for (int j = lane; j < c4; j += 64) {
-        const f32x4 a = rv[j], b = qv[j];
+        const f32x4 a = stored_row4(rows_f32, rows_b16, id, ld, j), b = qv[j];
         acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc);
         acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
       }
@@ -174,7 +183,7 @@ __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ r
 template <bool RERANK>
 __global__ __launch_bounds__(1024) void final_sorted_kernel(const float* __restrict__ in_s, const int* __restrict__ in_i,
                                                             int n_lists, int kk, int k, long long row_offset,
-                                                            const float* __restrict__ rows_f32, int ld,
+                                                            const float* __restrict__ rows_f32, const uint16_t* __restrict__ rows_b16, int ld,
                                                             const float* __restrict__ qn,
                                                             long long* __restrict__ out_idx,
                                                             float* __restrict__ out_dist,
@@ -206,7 +215,7 @@ __global__ __launch_bounds__(1024) void final_sorted_kernel(const float* __restr
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         if (ids[t] != kIdxSentinel) {  // wave-uniform
-          const f32x4 a = reinterpret_cast<const f32x4*>(rows_f32 + (size_t)ids[t] * ld)[j];
+          const f32x4 a = stored_row4(rows_f32, rows_b16, ids[t], ld, j);
           acc[t] = fmaf(a.x, b.x, acc[t]); acc[t] = fmaf(a.y, b.y, acc[t]);
           acc[t] = fmaf(a.z, b.z, acc[t]); acc[t] = fmaf(a.w, b.w, acc[t]);
         }

@@ -249,10 +249,10 @@ int finish_search(vdb_t* h, const WsPtrs& W, int b, int n_parts, int kk, int k, 
     }
     if (kp)
       hipLaunchKernelGGL((final_sorted_kernel<true>), dim3(b), dim3(1024), 0, st, cur_s, cur_i, lists, kk, k,
-                         (long long)h->row_offset, h->rows_f32, h->ld, qn, (long long*)oi, od);
+                         (long long)h->row_offset, h->keep_f32 ? (const float*)h->rows_f32 : (const float*)nullptr, (const uint16_t*)h->rows_bf16, h->ld, qn, (long long*)oi, od);
     else
       hipLaunchKernelGGL((final_sorted_kernel<false>), dim3(b), dim3(1024), 0, st, cur_s, cur_i, lists, kk, k,
-                         (long long)h->row_offset, (const float*)nullptr, h->ld, qn, (long long*)oi, od);
+                         (long long)h->row_offset, (const float*)nullptr, (const uint16_t*)nullptr, h->ld, qn, (long long*)oi, od);
     HIP_TRY(h, hipGetLastError());
     return VDB_OK;
   }
@@ -266,7 +266,7 @@ int finish_search(vdb_t* h, const WsPtrs& W, int b, int n_parts, int kk, int k, 
     lists = gx;
   }
   if (kp)
-    hipLaunchKernelGGL(rerank_kernel, dim3(b), dim3(256), (size_t)kk * 8, st, h->rows_f32, h->ld, qn, cur_i, kk, k,
+    hipLaunchKernelGGL(rerank_kernel, dim3(b), dim3(256), (size_t)kk * 8, st, h->keep_f32 ? (const float*)h->rows_f32 : (const float*)nullptr, (const uint16_t*)h->rows_bf16, h->ld, qn, cur_i, kk, k,
                        (long long)h->row_offset, (long long*)oi, od);
   else
     hipLaunchKernelGGL(finalize_kernel, dim3(b), dim3(256), (size_t)kk * 8, st, cur_s, cur_i, kk, k,
@@ -323,11 +323,11 @@ int mfma_search(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
   const int* ovf = a.cand_cnt + (size_t)b * kMfCntStrideC;
   if (kp)
     hipLaunchKernelGGL((final_sorted_kernel<true>), dim3(b), dim3(1024), 0, st, (const float*)a.list_s, (const int*)a.list_i, 1, kk, k,
-                       (long long)h->row_offset, (const float*)h->rows_f32, h->ld, qn, (long long*)out_idx, out_dist,
+                       (long long)h->row_offset, h->keep_f32 ? (const float*)h->rows_f32 : (const float*)nullptr, (const uint16_t*)h->rows_bf16, h->ld, qn, (long long*)out_idx, out_dist,
                        ovf, (const float*)a.part_s, (const int*)a.part_i, pl.fb_splits);
   else
     hipLaunchKernelGGL((final_sorted_kernel<false>), dim3(b), dim3(1024), 0, st, (const float*)a.list_s, (const int*)a.list_i, 1, kk, k,
-                       (long long)h->row_offset, (const float*)nullptr, h->ld, qn, (long long*)out_idx, out_dist,
+                       (long long)h->row_offset, (const float*)nullptr, (const uint16_t*)nullptr, h->ld, qn, (long long*)out_idx, out_dist,
                        ovf, (const float*)a.part_s, (const int*)a.part_i, pl.fb_splits);
   HIP_TRY(h, hipGetLastError());
   return VDB_OK;
@@ -492,7 +492,7 @@ int check_search_args(vdb_t* h, const void* q, int b, int k, int kp, const void*
   if (b < 0 || (b > 0 && (!q || !oi || !od))) return fail(h, VDB_ERR_ARG, "search: NULL buffer");
   if (k < 1 || k > VDB_MAX_K) return fail(h, VDB_ERR_ARG, "search: k must be in [1,1024]");
   if (kp != 0 && (kp < k || kp > VDB_MAX_K)) return fail(h, VDB_ERR_ARG, "search: rerank_kprime must be 0 or in [k,1024]");
-  if (kp != 0 && !(h->dtype == VDB_BF16 && h->keep_f32)) return fail(h, VDB_ERR_STATE, "search: rerank needs a bf16 store created with keep_f32_for_rerank");
+  if (kp != 0 && h->dtype != VDB_BF16) return fail(h, VDB_ERR_STATE, "search: rerank_kprime needs a bf16 store");   // without an fp32 copy the k' candidates are re-scored against the bf16 rows
   return VDB_OK;
 }
 
