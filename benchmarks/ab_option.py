@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """A/B of one engine option inside ONE process, arms interleaved (boxes differ by +-2 %, runs on one box by ~1 %):
-  python3 benchmarks/ab_option.py --option mfma_shape16 --values 0,1 --batch 1024 [--rows N] [--rounds 6] [--iters 10]"""
+  python3 benchmarks/ab_option.py --option mfma_shape16 --values 0,1 --batch 1024 [--rows N] [--rounds 6] [--iters 10]
+  python3 benchmarks/ab_option.py --arms "mfma_split_x1000=500,mfma_append_cap=16384;mfma_split_x1000=650,mfma_append_cap=32768" --batch 32"""
 import argparse
 import json
 import os
@@ -17,7 +18,8 @@ from vectordb_amd import FlatIndex, SynthSpec  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--option", required=True)
+    ap.add_argument("--option", default=None)
+    ap.add_argument("--arms", default=None, help="instead of --option/--values: arms separated by ';', each a comma list of NAME=VALUE")
     ap.add_argument("--values", default="0,1")
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--rows", type=int, default=10_000_000)
@@ -38,12 +40,20 @@ def main():
     oi = torch.empty((b, k), dtype=torch.int64, device="cuda")
     od = torch.empty((b, k), dtype=torch.float32, device="cuda")
     st = torch.cuda.current_stream().cuda_stream
-    vals = [int(v) for v in args.values.split(",")]
+    if args.arms:
+        vals = [a.strip() for a in args.arms.split(";") if a.strip()]
+    else:
+        vals = [int(v) for v in args.values.split(",")]
     res = {v: [] for v in vals}
     ref = None
     for r in range(args.rounds + 1):
         for v in vals:
-            ix.set_option(args.option, v)
+            if args.arms:
+                for kv in v.split(","):
+                    name, _, val = kv.partition("=")
+                    ix.set_option(name.strip(), int(val))
+            else:
+                ix.set_option(args.option, v)
             ix.search_device(q.data_ptr(), b, k, kp, oi.data_ptr(), od.data_ptr(), st)
             torch.cuda.synchronize()
             if ref is None:

@@ -252,7 +252,8 @@ int vdb_timing_stats(vdb_t* h, int64_t* n_searches, double* scan_ms_sum, double*
  * "mfma_cost_model" (default 1: a batch takes the MFMA path only where it is faster than ceil(b/4) GEMV passes;
  * 0: whenever it is supported), "mfma_variant" (4: 256x128 tiles only; 5: + 256x256 tiles; 6, default: + the streaming
  * kernel for <= 64 queries), "stream_nt_loads", "mfma_append_cap", "mfma_split_x1000" (where the sample pass sits between the dense sample and
- * the full pass; 500 = geometric mean, measured best), "mfma_force_fallback".
+ * the full pass: 0, the default, = 500, the geometric mean, for the tiled kernels and 600 for the streaming kernel, both measured
+ * best; or 100..900), "mfma_force_fallback".
  * Unknown names return VDB_ERR_ARG. */
 int vdb_set_option(vdb_t* h, const char* name, int64_t value);
 

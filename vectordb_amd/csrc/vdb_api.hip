@@ -93,8 +93,12 @@ struct vdb {
   int mfma_skip_sample = 1;       // 1: the last of two passes leaves out the sample pass's tiles
   void* pin = nullptr; size_t pin_bytes = 0;                                     // pinned host staging for small host-pointer searches
   DevBuf w_mask;                                                                // host-supplied eligibility bitmap (vdb_search_masked)
-  int mfma_append_cap = 16384;   // candidate buffer entries per query
-  int mfma_split_x1000 = 500;    // two append passes: the sample pass covers span^(x/1000) times the dense sample (500 = geometric mean)
+  int mfma_append_cap = 16384;   // candidate buffer entries per query (also sets how far a pass may grow: cap / 4k')
+  int mfma_split_x1000 = 0;      // two append passes: the sample pass covers span^(x/1000) times the dense sample; 0 = by kernel
+                                 // family: 500 (tiled kernels: the geometric mean, the sample pass costs flops) or 600 (streaming
+                                 // kernel: the sample pass costs no extra bytes — the last pass leaves its tiles out — and every hit
+                                 // of the last pass stalls a wave's load ring: 2.57 -> 2.46 ms at 3 queries, 2.52 -> 2.45 at 64, 10M rows;
+                                 // 650 is as fast but fills the sample pass's candidate buffers to half their capacity)
   int mfma_variant = 6;          // 4 = warp-specialised 256x128 tile (scan_mfma4.h); 5 = + the 256x256 tile (scan_mfma5.h)
                                  // where it pads the batch <= 1.5x further; 6 = + the streaming kernel (scan_stream.h) for <= 64 queries
   int mfma_last_b = 0;           // batch size of the last MFMA search (locates its overflow flag)
@@ -305,7 +309,7 @@ int mfma_search(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
   MfSearchArgs a;
   a.rows_bf16 = (const unsigned char*)h->rows_bf16; a.n_rows = n_rows; a.qn = qn; a.b = b; a.kk = kk;
   a.self0 = self_row0 >= 0 ? (int)self_row0 : -1;
-  a.n_cu = h->n_cu; a.variant = h->mfma_variant; a.cap = cap; a.split_x1000 = h->mfma_split_x1000;
+  a.n_cu = h->n_cu; a.variant = h->mfma_variant; a.cap = cap; a.split_x1000 = h->mfma_split_x1000 ? h->mfma_split_x1000 : (pl.variant == 6 ? 600 : 500);
   a.skip_sample = h->mfma_skip_sample; a.force_fallback = h->mfma_force_fallback; a.ablate = h->mfma_ablate; a.stream_nt = h->stream_nt; a.stream_blocks_per_cu = h->stream_blocks_per_cu; a.shape16 = h->mfma_shape16; a.stream_lds = h->stream_lds;
   a.qb16 = (unsigned char*)h->w_mfma.p;
   a.cand_s = (float*)h->w_cand_s.p; a.cand_i = (int*)h->w_cand_i.p; a.cand_cnt = (int*)h->w_cand_cnt.p;
@@ -334,20 +338,20 @@ int mfma_search(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
 }
 
 // Which path serves a bf16 768-d batch faster?  Coefficients measured on MI355X (10M and 1M rows, round 2):
-// a GEMV pass costs a launch (~12 us) plus the corpus at ~6.7 TB/s, times 1.0 / 1.06 / 1.64 for 1 / 2 / 4
-// queries per pass (b = 3 runs as 2 + 1).  The batched path costs ~110 us of launches (dense sample, selects,
-// append passes) plus, per row: the streaming kernel (<= 64 queries) the corpus at ~6.6 TB/s (whole lines through
+// a GEMV pass costs a launch (~12 us) plus the corpus at ~6.95 TB/s, times 1.0 / 1.06 / 1.64 for 1 / 2 / 4
+// queries per pass (b = 3 runs as 2 + 1).  The batched path costs ~95 us of launches (dense sample, selects,
+// append passes) plus, per row: the streaming kernel (<= 64 queries) the corpus at ~6.65 TB/s (whole lines through
 // its LDS ring; 6.0 in the register form); the tiled kernels 0.25 ns per 128-query tile or 0.36 (+0.05) ns per
 // 256-query tile.
-// Measured at 10M rows: b = 2 GEMV 2.34 ms vs streaming 2.45; b = 4 3.70 vs 2.46; b = 64 58.6 vs 2.45;
+// Measured at 10M rows: b = 2 GEMV 2.34 ms vs streaming 2.41; b = 4 3.70 vs 2.41; b = 64 58.6 vs 2.45-2.50;
 // b = 65 tiled 3.03; b = 128 3.25.
 bool mfma_is_faster(int b, int n_rows, int variant_opt) {
-  const double pass = 12e-6 + (double)n_rows * kMfRowBytesC / 6.7e12;
+  const double pass = 12e-6 + (double)n_rows * kMfRowBytesC / 6.95e12;
   const int r = b & 3;
   const double gemv = pass * (1.64 * (b >> 2) + (r == 3 ? 2.06 : r == 2 ? 1.06 : r == 1 ? 1.0 : 0.0));
   const MfPlan pl = mfma_plan(b, n_rows, 256, variant_opt);
   double mfma;
-  if (pl.variant == 6) mfma = 110e-6 + (double)n_rows * kMfRowBytesC / 6.6e12;
+  if (pl.variant == 6) mfma = 95e-6 + (double)n_rows * kMfRowBytesC / 6.65e12;
   else if (pl.variant == 5) mfma = 100e-6 + (double)n_rows * (0.36e-9 * pl.n_qt + 0.05e-9);
   else mfma = 100e-6 + (double)n_rows * 0.25e-9 * pl.n_qt;
   return mfma < gemv;
@@ -1365,7 +1369,7 @@ int vdb_set_option(vdb_t* h, const char* name, int64_t value) {
     h->mfma_variant = (int)value; return VDB_OK;
   }
   if (!strcmp(name, "mfma_split_x1000")) {
-    if (value < 100 || value > 900) return fail(h, VDB_ERR_ARG, "mfma_split_x1000 must be in [100,900]");
+    if (value != 0 && (value < 100 || value > 900)) return fail(h, VDB_ERR_ARG, "mfma_split_x1000 must be 0 (by kernel family) or in [100,900]");
     h->mfma_split_x1000 = (int)value; return VDB_OK;
   }
   if (!strcmp(name, "mfma_skip_sample")) { h->mfma_skip_sample = value != 0; return VDB_OK; }
