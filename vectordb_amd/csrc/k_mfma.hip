@@ -74,9 +74,8 @@ hipError_t mfma_search_launch(const MfSearchArgs& a, int* skipped_tiles) {
   const MfGrid fb = mf_grid(a.n_cu, n_qt_fb, n_tiles, 64);
 
   hipLaunchKernelGGL(queries_to_bf16_kernel, dim3(std::min(1024, (pl.b_pad * kMfDim + 255) / 256)), dim3(256), 0, st,
-                     a.qn, b, pl.b_pad, (uint16_t*)a.qb16);
+                     a.qn, b, pl.b_pad, (uint16_t*)a.qb16, ovf);   // also clears the overflow flag
   MF_TRY(hipGetLastError());
-  MF_TRY(hipMemsetAsync(ovf, 0, 4, st));
 
   // one pass of whichever kernel serves this batch; mode 0 = dense sample, 1 = append
   auto launch_pass = [&](int mode, long long pass_tiles, int stride, int skip_n) -> hipError_t {
@@ -99,7 +98,7 @@ hipError_t mfma_search_launch(const MfSearchArgs& a, int* skipped_tiles) {
     MF_TRY(launch_pass(0, t_cur, stride, 0));
     // rows of the dense matrix beyond the sampled tiles were never written: select over t_cur*256 columns only
     // n_tiles == t_cur: the dense pass saw the whole store and the next pass is the last; either way a valid lower bound suffices
-    hipLaunchKernelGGL(dense_lower_bound_kernel, dim3(b), dim3(64), 0, st, dense, kMf3DenseLd, (int)t_cur * kMfBM, kk, thr);
+    hipLaunchKernelGGL(dense_lower_bound_kernel, dim3(b), dim3(64), 0, st, dense, kMf3DenseLd, (int)t_cur * kMfBM, kk, thr, cand_cnt);   // also clears the append counters
     MF_TRY(hipGetLastError());
   }
   // append passes over geometrically growing strided samples; the growth factor per pass is
@@ -121,12 +120,12 @@ hipError_t mfma_search_launch(const MfSearchArgs& a, int* skipped_tiles) {
     int skip_n = 0;
     long long pass_tiles = t_next;
     if (last && seeded) { stride = seed_stride; skip_n = seed_n; pass_tiles = n_tiles - skip_n; if (skipped_tiles) *skipped_tiles = skip_n; }
-    MF_TRY(hipMemsetAsync(cand_cnt, 0, (size_t)b * kMfCntStride * 4, st));
+    // (the append counters are zero here: cleared by dense_lower_bound_kernel, then by each non-final selection)
     if (pass_tiles > 0) MF_TRY(launch_pass(1, pass_tiles, stride, skip_n));
     // the sample pass of a two-pass search keeps its sorted list when the last pass can leave its tiles out
     const bool keep = !last && n_pass == 2 && stride >= 2 && a.skip_sample;
     hipLaunchKernelGGL(select_kth_kernel, dim3(b), dim3(1024), 0, st, (const float*)cand_s, (const int*)cand_i,
-                       (const int*)cand_cnt, cap, kk, thr, (last || keep) ? (last ? a.list_s : a.seed_s) : (float*)nullptr,
+                       cand_cnt, last ? 0 : 1, cap, kk, thr, (last || keep) ? (last ? a.list_s : a.seed_s) : (float*)nullptr,
                        (last || keep) ? (last ? a.list_i : a.seed_i) : (int*)nullptr, ovf,
                        (last && seeded) ? (const float*)a.seed_s : (const float*)nullptr,
                        (last && seeded) ? (const int*)a.seed_i : (const int*)nullptr);

@@ -56,8 +56,10 @@ __host__ __device__ constexpr size_t mf_smem_bytes() {
 }
 
 #ifdef VDB_MFMA_HOST_TU   // kernels of the orchestrating TU (k_mfma.hip) only: every pass-kernel TU includes this header
-// fp32 normalised queries [b][768] -> bf16 [b_pad][768] (rows >= b zero)
-__global__ void queries_to_bf16_kernel(const float* __restrict__ qn, int b, int b_pad, uint16_t* __restrict__ out) {
+// fp32 normalised queries [b][768] -> bf16 [b_pad][768] (rows >= b zero); the first kernel of a batched search, so it
+// also clears the batch's overflow flag (one launch less than a memset)
+__global__ void queries_to_bf16_kernel(const float* __restrict__ qn, int b, int b_pad, uint16_t* __restrict__ out, int* __restrict__ clear_flag) {
+  if (clear_flag && blockIdx.x == 0 && threadIdx.x == 0) *clear_flag = 0;
   const long long total = (long long)b_pad * kMfDim;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int r = (int)(i / kMfDim);

@@ -34,8 +34,9 @@ constexpr int kMf3DenseLd = kMf3DenseTiles * kMfBM;
 // list -> list_*[q][kk].  Candidates: dense scores (cand_i == nullptr, index = position) or
 // an append buffer with cand_cnt[q] entries (capacity cap; more -> *overflow = 1), optionally merged with a
 // seed list (seed_*).
+// zero_cnt != 0: the query's append counter is cleared for the next pass once every thread has read it.
 __global__ __launch_bounds__(1024) void select_kth_kernel(const float* __restrict__ cand_s, const int* __restrict__ cand_i,
-                                                          const int* __restrict__ cand_cnt, int cap_or_n, int kk,
+                                                          int* cand_cnt, int zero_cnt, int cap_or_n, int kk,
                                                           float* __restrict__ thr_out, float* __restrict__ list_s,
                                                           int* __restrict__ list_i, int* __restrict__ overflow,
                                                           const float* __restrict__ seed_s = nullptr,
@@ -78,6 +79,7 @@ __global__ __launch_bounds__(1024) void select_kth_kernel(const float* __restric
     // when the last pass skips them); -inf / sentinel entries behind its end
     if (seed_s) tk.merge_sorted(lane < kk ? seed_s[(size_t)q * kk + lane] : -INFINITY, lane < kk ? seed_i[(size_t)q * kk + lane] : kIdxSentinel);
     if (lane == 0) thr_out[q] = tk.thr_s;
+    if (lane == 0 && zero_cnt && cand_cnt) cand_cnt[q * kMfCntStride] = 0;   // (behind the tree's barriers: every thread has its count)
     if (list_s) tk.store(list_s + (size_t)q * kk, list_i + (size_t)q * kk);
   }
 }
@@ -87,8 +89,9 @@ __global__ __launch_bounds__(1024) void select_kth_kernel(const float* __restric
 // row with at least kk sampled rows at or above it, hence <= the true k'-th best.  A little looser than the
 // exact k'-th best of the sample (1.5 % instead of 1 % of the next pass's scores pass at kk = 40 over 4096
 // rows) but 10x cheaper than an exact selection over the dense scores (127 us at B = 1024).
+// Also clears the query's append counter for the first append pass.
 __global__ __launch_bounds__(64) void dense_lower_bound_kernel(const float* __restrict__ scores, int ld, int n, int kk,
-                                                               float* __restrict__ thr_out) {
+                                                               float* __restrict__ thr_out, int* __restrict__ cand_cnt) {
   const int q = blockIdx.x;
   const int lane = threadIdx.x;
   const float* cs = scores + (size_t)q * ld;
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(64) void dense_lower_bound_kernel(const float* __re
       v = (((lane & j) == 0) == ((lane & k) == 0)) ? fmaxf(v, o) : fminf(v, o);
     }
   const float t = __shfl(v, kk - 1);
-  if (lane == 0) thr_out[q] = t;
+  if (lane == 0) { thr_out[q] = t; cand_cnt[q * kMfCntStride] = 0; }
 }
 #endif
 
