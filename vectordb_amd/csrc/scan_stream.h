@@ -270,6 +270,24 @@ __global__ __launch_bounds__(kStThreads, 2) void scan_stream_lds_kernel(
 #pragma unroll
   for (int j = 0; j < kStSlabs; ++j) issue_slab(pc, j, j);
 
+  constexpr int kStPend = 2;
+  float pend_v[kStPend];
+  int pend_row[kStPend], pend_q[kStPend];
+  int pend_n = 0;
+#pragma unroll
+  for (int sl = 0; sl < kStPend; ++sl) { pend_v[sl] = 0.f; pend_row[sl] = 0; pend_q[sl] = 0; }
+  auto flush_pending = [&]() {
+    int pos[kStPend];
+#pragma unroll
+    for (int sl = 0; sl < kStPend; ++sl) pos[sl] = sl < pend_n ? atomicAdd(&cand_cnt[pend_q[sl] * kMfCntStride], 1) : cap;   // all in flight, one wait
+    // the atomics may return out of order with the DMA loads: drain, so that the counted waits of the next tile count loads only
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int sl = 0; sl < kStPend; ++sl)
+      if (pos[sl] < cap) { cand_s[(size_t)pend_q[sl] * cap + pos[sl]] = pend_v[sl]; cand_i[(size_t)pend_q[sl] * cap + pos[sl]] = pend_row[sl]; }
+    pend_n = 0;
+  };
+
   for (;;) {
     const long long un = u + nw;
     const bool has_next = un < n_units;
@@ -324,7 +342,9 @@ __global__ __launch_bounds__(kStThreads, 2) void scan_stream_lds_kernel(
         any = any || (mx >= thr_bits[nq]);
       }
       if (__ballot(any) != 0ull) {
-        int pos[NQ][4];
+        // A hit waits in its lane's registers (kStPend places) until some lane needs one more; then every waiting hit
+        // reserves its slot at once (scan_mfma5.h does the same).  The returning atomics share the counter with the DMA
+        // loads, so a flush drains the wave's load ring: once per ~a dozen hits this way instead of once per tile with a hit.
 #pragma unroll
         for (int nq = 0; nq < NQ; ++nq) {
           const int qg = nq * 16 + m;
@@ -332,27 +352,23 @@ __global__ __launch_bounds__(kStThreads, 2) void scan_stream_lds_kernel(
           for (int reg = 0; reg < 4; ++reg) {
             const int row = row0 + 4 * c + reg;
             const bool pass = (acc[nq][reg] >= thr[nq]) && (row < n_rows) && (qg < b) && !(self0 >= 0 && row == self0 + qg);
-            pos[nq][reg] = pass ? atomicAdd(&cand_cnt[qg * kMfCntStride], 1) : cap;
+            if (__ballot(pass) == 0ull) continue;
+            if (__ballot(pass && pend_n == kStPend) != 0ull) flush_pending();
+            if (pass) {
+#pragma unroll
+              for (int sl = 0; sl < kStPend; ++sl)
+                if (pend_n == sl) { pend_v[sl] = acc[nq][reg]; pend_row[sl] = row; pend_q[sl] = qg; }
+              ++pend_n;
+            }
           }
         }
-        // the atomics share the counter with the DMA loads and may return out of order with them: drain, so that the
-        // counted waits of the next tile count loads only
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int nq = 0; nq < NQ; ++nq) {
-          const int qg = nq * 16 + m;
-#pragma unroll
-          for (int reg = 0; reg < 4; ++reg)
-            if (pos[nq][reg] < cap) {
-              cand_s[(size_t)qg * cap + pos[nq][reg]] = acc[nq][reg];
-              cand_i[(size_t)qg * cap + pos[nq][reg]] = row0 + 4 * c + reg;
-            }
-        }
+        if (self0 == -2) flush_pending();   // diagnostic (mfma_ablate bit 128): one flush per tile with a hit, as before the waiting places
       }
     }
     if (!has_next) break;
     u = un; row0 = row0n; pc = pn;
   }
+  if (MODE == 1) flush_pending();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing refills must land before the LDS is handed on
 }
 
