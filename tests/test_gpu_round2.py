@@ -436,3 +436,37 @@ def test_batched_search_on_a_store_without_the_fp32_copy(hip_lib, oracle_mod, co
     idx, dist = sh.search(queries[:64], 10, 40)
     check_topk(idx, dist, r_idx[:64], r_dist[:64], r_sc[:64], src, qn[:64], what="bf16-only sharded batched")
     sh.close()
+
+
+def test_add_path_kernels_against_the_oracle(hip_lib, oracle_mod):
+    """The add path's two normalisation kernels (rows in registers with 16-byte accesses for dims that are a multiple of 4 up
+    to 2048 on aligned input; the scalar kernel otherwise): the stored fp32 rows are the oracle's within 1 ulp, the stored
+    bf16 rows its rounding of them, whichever kernel ran — host rows, device rows, and a device pointer that is only
+    4-byte aligned."""
+    import torch
+    rng = np.random.default_rng(12)
+    for dim in (4, 100, 384, 768, 1024, 2048, 2052, 770, 7):
+        n = 1000
+        rows = (rng.standard_normal((n, dim)) * rng.uniform(0.01, 100.0, (n, 1))).astype(np.float32)
+        rows[17] = 0.0                                             # a zero row stays zero (1 / (0 + 1e-30) * 0)
+        ref = oracle_mod.normalize_rows(rows)
+        ulp = lambda a, b: np.max(np.abs(a.view(np.int32).astype(np.int64) - b.view(np.int32).astype(np.int64)))   # noqa: E731
+        for how in ("host", "device", "device_unaligned"):
+            ix = FlatIndex(dim, "f32")
+            bx = FlatIndex(dim, "bf16", False)
+            if how == "host":
+                ix.add(rows); bx.add(rows)
+            else:
+                flat = torch.empty(n * dim + 1, dtype=torch.float32, device="cuda")
+                off = 1 if how == "device_unaligned" else 0
+                t = flat[off:off + n * dim].view(n, dim)
+                t.copy_(torch.from_numpy(rows))
+                torch.cuda.synchronize()
+                assert (t.data_ptr() % 16 == 0) == (off == 0)
+                ix.add_device(t.data_ptr(), n); bx.add_device(t.data_ptr(), n)
+            got = ix.fetch(np.arange(n))
+            assert ulp(got, ref) <= 1 and np.all(got[17] == 0), (dim, how)
+            got_b = bx.fetch(np.arange(n))
+            ref_b = oracle_mod.round_bf16(got)                    # bf16 of what the fp32 path stored
+            assert np.array_equal(got_b, ref_b), (dim, how)
+            ix.close(); bx.close()

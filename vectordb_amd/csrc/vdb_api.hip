@@ -192,7 +192,20 @@ int normalize_into_store(vdb_t* h, const float* raw_dev, int in_ld, int64_t n, h
   const int blocks = (int)std::min<int64_t>((n + 3) / 4, (int64_t)h->n_cu * 8);
   float* of = h->keep_f32 ? h->rows_f32 + (size_t)h->n * h->ld : nullptr;
   uint16_t* ob = h->dtype == VDB_BF16 ? h->rows_bf16 + (size_t)h->n * h->ld : nullptr;
-  hipLaunchKernelGGL(normalize_rows_kernel, dim3(blocks), dim3(256), 0, st, raw_dev, in_ld, (long long)n, h->dim, h->ld, of, ob);
+  // rows held in registers, 16-byte accesses: dim a multiple of 4 up to 2048, aligned input (every call site but a
+  // caller's odd device pointer); otherwise the scalar kernel
+  const int nv = (h->ld / 4 + 63) / 64;
+  if ((h->dim & 3) == 0 && (in_ld & 3) == 0 && h->ld <= 2048 && (((uintptr_t)raw_dev) & 15) == 0) {
+    switch (nv <= 1 ? 1 : nv <= 2 ? 2 : nv <= 3 ? 3 : nv <= 4 ? 4 : 8) {
+      case 1: hipLaunchKernelGGL((normalize_rows_vec_kernel<1>), dim3(blocks), dim3(256), 0, st, raw_dev, in_ld, (long long)n, h->dim, h->ld, of, ob); break;
+      case 2: hipLaunchKernelGGL((normalize_rows_vec_kernel<2>), dim3(blocks), dim3(256), 0, st, raw_dev, in_ld, (long long)n, h->dim, h->ld, of, ob); break;
+      case 3: hipLaunchKernelGGL((normalize_rows_vec_kernel<3>), dim3(blocks), dim3(256), 0, st, raw_dev, in_ld, (long long)n, h->dim, h->ld, of, ob); break;
+      case 4: hipLaunchKernelGGL((normalize_rows_vec_kernel<4>), dim3(blocks), dim3(256), 0, st, raw_dev, in_ld, (long long)n, h->dim, h->ld, of, ob); break;
+      default: hipLaunchKernelGGL((normalize_rows_vec_kernel<8>), dim3(blocks), dim3(256), 0, st, raw_dev, in_ld, (long long)n, h->dim, h->ld, of, ob); break;
+    }
+  } else {
+    hipLaunchKernelGGL(normalize_rows_kernel, dim3(blocks), dim3(256), 0, st, raw_dev, in_ld, (long long)n, h->dim, h->ld, of, ob);
+  }
   HIP_TRY(h, hipGetLastError());
   return VDB_OK;
 }
