@@ -45,6 +45,8 @@ def parse_args():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traffic-pass", action="store_true",
+                    help="skip the rocprofv3 --pmc FETCH_SIZE pass (a child process, run before this one touches the GPU) that fills roofline.traffic")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--nt", type=int, default=-1)
     ap.add_argument("--force-collective", action="store_true",
@@ -126,6 +128,57 @@ def _chroma_note():
     return "chromadb importable: not timed by this script"
 
 
+def traffic_pass(args):
+    """HBM bytes per launch of the dominant kernels, measured: a short run of this same script as a CHILD process under
+    `rocprofv3 --pmc FETCH_SIZE` (a counter pass of its own, no tracing), started before this process touches the GPU.
+    FETCH_SIZE is in KiB and on gfx950 tallies a wide coalesced 16 B/lane stream at half its bytes
+    (MI355X_MICROARCH.md, HBM): bytes = 2 * 1024 * FETCH_SIZE.  Returns {kernel family: bytes per launch} or a reason."""
+    import csv
+    import glob
+    import shutil
+    import signal
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    d = tempfile.mkdtemp(prefix="vdb_pmc_", dir="/tmp")
+    cmd = [exe, "--pmc", "FETCH_SIZE", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+           "--gpus", "1", "--steps", "4", "--warmup", "1", "--steps2", "2", "--no-cpu-baseline", "--no-traffic-pass",
+           "--rows", str(args.rows), "--dim", str(args.dim), "--batch", str(args.batch), "--batch2", str(args.batch2),
+           "--k", str(args.k), "--kprime", str(args.kprime), "--dtype", args.dtype, "--seed", str(args.seed)]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["TMPDIR"] = "/tmp"
+    try:
+        p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+        try:
+            rc = p.wait(timeout=240)
+        except subprocess.TimeoutExpired:
+            os.killpg(p.pid, signal.SIGKILL)
+            p.wait()
+            return None, "the counter pass did not finish in 240 s"
+        if rc != 0:
+            return None, f"the counter pass exited with {rc}"
+        per = {}
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            with open(f, newline="") as fh:
+                for r in csv.DictReader(fh):
+                    if r.get("Counter_Name") == "FETCH_SIZE":
+                        per.setdefault(r["Kernel_Name"], []).append(2.0 * 1024.0 * float(r["Counter_Value"]))
+        out = {}
+        for name, vals in per.items():
+            fam = next((f for f in ("scan_topk_kernel", "scan_mfma_wide16_kernel<1", "scan_mfma_wide_kernel<1", "scan_mfma_ws_kernel<1",
+                                    "scan_stream_lds_kernel<1", "scan_stream_kernel<1", "probe_read_kernel") if f in name), None)
+            if fam is None:
+                continue
+            big = [v for v in vals if v >= 0.5 * max(vals)]      # the batched kernels launch twice per batch: the last pass is the large one
+            out[fam.split("<")[0]] = {"bytes_per_launch": sum(big) / len(big), "launches": len(big)}
+        return (out, "rocprofv3 --pmc FETCH_SIZE child pass of this command (4 + 2 steps), bytes = 2*1024*FETCH_SIZE") if out else (None, "no FETCH_SIZE rows in the counter pass's output")
+    except OSError as e:
+        return None, f"the counter pass could not start: {e}"
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def dist_rank0():
     return int(os.environ.get("RANK", "0")) == 0
 
@@ -165,7 +218,11 @@ def measure(sh, args, b, steps, warmup, qspec, device, world, n_local):
         # every batch's exchange and merge still complete inside the timed region (device sync)
         return sh.search(qpool[i % n_sets], k, kp, wait=args.sync_exchange)
 
-    for i in range(warmup):
+    # Settle, then the W warm-up steps.  A fresh process sometimes runs its first few hundred milliseconds of kernels ~2 %
+    # slow (clocks still ramping: two of four otherwise identical runs with 20 warm-up steps on one box); the same fixed
+    # number of untimed steps on every rank (the steps are collective) takes the timed region past that.
+    settle = 150 if b <= 64 else 8
+    for i in range(settle + warmup):
         step(i)
     torch.cuda.synchronize()
     sh.local.set_option("timing_ring", max(1, min(steps, 65536)))
@@ -240,8 +297,7 @@ def measure(sh, args, b, steps, warmup, qspec, device, world, n_local):
         # search's own shape with the scores written out, and a square one (the chip is power-limited)
         roof["library_gemm_tflops_random_operands"] = {"%dx262144x%d" % (b, dim): _library_gemm(b, 1 << 18, dim),
                                                        "8192x8192x8192": _library_gemm(8192, 8192, 8192)}
-    # HBM bytes per launch: only a rocprofv3 --pmc FETCH_SIZE pass can tell, and this invocation is not one
-    # (profiles/r02_pmc_traffic.json holds the separate pass of this same command)
+    # HBM bytes per launch: only a rocprofv3 --pmc FETCH_SIZE pass can tell; main() fills this in from traffic_pass()
     roof["traffic"] = None
     roof["kernel"] = kernel
     roof["kernel_avg_ms"] = scan_ms
@@ -249,7 +305,7 @@ def measure(sh, args, b, steps, warmup, qspec, device, world, n_local):
     roof["merge_rerank_avg_ms"] = tstats["merge_ms_sum"] / max(tstats["n"], 1)
     del qpool
     return {
-        "value": steps * b / elapsed, "unit": "queries/s", "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
+        "value": steps * b / elapsed, "unit": "queries/s", "steps": steps, "warmup": warmup, "settle_steps_before_warmup": settle, "ms_per_step": 1e3 * elapsed / steps,
         "batch": b, "roofline": roof,
         "checks": {"planted_neighbour_first_and_ascending": planted_ok,
                    "measured_peak_is_a_ceiling": (roof.get("frac_of_measured_peak") or 0) <= 1.02,
@@ -267,6 +323,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         self_launch(args)                      # does not return
+    traffic, traffic_note = None, "not collected (--no-traffic-pass, or more than one rank)"
+    if world == 1 and not args.no_traffic_pass:
+        traffic, traffic_note = traffic_pass(args)          # a child process; nothing here has touched the GPU yet
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
 
@@ -341,6 +400,13 @@ def main():
             second["metric"] = f"QPS @k={k}, {n // 1_000_000}Mx{dim} corpus, batch {args.batch2}"
             second["workload"] = workload(args.batch2)
             out[f"batch{args.batch2}"] = second
+        # HBM bytes per launch of each block's dominant kernel, from the counter pass run before the timed work (or null)
+        for blk in [out] + ([second] if second is not None else []):
+            fam = blk["roofline"]["kernel"].split("<")[0].split(" ")[0]
+            got = (traffic or {}).get(fam)
+            blk["roofline"]["traffic"] = got["bytes_per_launch"] if got else None
+            blk["roofline"]["traffic_unit"] = "HBM bytes per launch of " + fam
+            blk["roofline"]["traffic_source"] = traffic_note if got or traffic is None else "the counter pass saw no launch of " + fam
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dim, k, n, args.seed)
         print(json.dumps(out), flush=True)
