@@ -166,6 +166,22 @@ __global__ __launch_bounds__(kWsThreads) void scan_mfma_ws_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
+  constexpr int kWsPend = 2;
+  float pend_v[kWsPend];
+  int pend_row[kWsPend], pend_q[kWsPend];
+  int pend_n = 0;
+#pragma unroll
+  for (int sl = 0; sl < kWsPend; ++sl) { pend_v[sl] = 0.f; pend_row[sl] = 0; pend_q[sl] = 0; }
+  auto flush_pending = [&]() {
+    int pos[kWsPend];
+#pragma unroll
+    for (int sl = 0; sl < kWsPend; ++sl) pos[sl] = sl < pend_n ? atomicAdd(&cand_cnt[pend_q[sl] * kMfCntStride], 1) : cap;   // all in flight, one wait
+#pragma unroll
+    for (int sl = 0; sl < kWsPend; ++sl)
+      if (pos[sl] < cap) { cand_s[(size_t)pend_q[sl] * cap + pos[sl]] = pend_v[sl]; cand_i[(size_t)pend_q[sl] * cap + pos[sl]] = pend_row[sl]; }
+    pend_n = 0;
+  };
+
   int slot = 0, round = 0, ks = 0, tile = 0;
   bool ok = true;
   for (int step = 0; step < total_steps; ++step) {
@@ -226,10 +242,16 @@ __global__ __launch_bounds__(kWsThreads) void scan_mfma_ws_kernel(
           if (__ballot(pass) == 0ull) continue;
           const int row = (int)tile_row0 + rloc;
           if (needs_mask) pass = pass && (row < n_rows) && (qg < b) && !(self0 >= 0 && row == self0 + qg);
+          // a hit waits in its lane's registers until some lane needs a third place; then all waiting hits reserve their
+          // slots together: one atomic round trip (~1-2 us) per flush instead of one per hit (scan_mfma5.h does the same)
+          if (__ballot(pass && pend_n == kWsPend) != 0ull) flush_pending();
           if (pass) {
-            const int pos = atomicAdd(&cand_cnt[qg * kMfCntStride], 1);
-            if (pos < cap) { cand_s[(size_t)qg * cap + pos] = v; cand_i[(size_t)qg * cap + pos] = row; }
+#pragma unroll
+            for (int sl = 0; sl < kWsPend; ++sl)
+              if (pend_n == sl) { pend_v[sl] = v; pend_row[sl] = row; pend_q[sl] = qg; }
+            ++pend_n;
           }
+          if (ablate & 128) flush_pending();   // diagnostic: one round trip per hit, as before the waiting places
         }
       }
     }
@@ -241,6 +263,7 @@ __global__ __launch_bounds__(kWsThreads) void scan_mfma_ws_kernel(
         for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
     ++tile;
   }
+  if (MODE == 1) flush_pending();
   if (!ok && lane == 0) *fail_flag = 1;
 }
 
