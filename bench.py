@@ -166,8 +166,8 @@ def traffic_pass(args):
                         per.setdefault(r["Kernel_Name"], []).append(2.0 * 1024.0 * float(r["Counter_Value"]))
         out = {}
         for name, vals in per.items():
-            fam = next((f for f in ("scan_topk_kernel", "scan_mfma_wide16_kernel<1", "scan_mfma_wide_kernel<1", "scan_mfma_ws_kernel<1",
-                                    "scan_stream_lds_kernel<1", "scan_stream_kernel<1", "probe_read_kernel") if f in name), None)
+            fam = next((f for f in ("scan_topk_kernel", "scan_mfma_wide16_kernel<1", "scan_mfma_ws_kernel<1",
+                                    "scan_stream_lds_kernel<1", "probe_read_kernel") if f in name), None)
             if fam is None:
                 continue
             big = [v for v in vals if v >= 0.5 * max(vals)]      # the batched kernels launch twice per batch: the last pass is the large one
@@ -267,8 +267,8 @@ def measure(sh, args, b, steps, warmup, qspec, device, world, n_local):
     esz = 2 if args.dtype == "bf16" else 4
     path = sh.local.get_stat("last_path")            # 0 = GEMV scan, 4/5 = MFMA pass kernels, 6 = streaming MFMA kernel
     scan_ms = tstats["scan_ms_sum"] / max(tstats["n"], 1)
-    kernel = {0: "scan_topk_kernel", 4: "scan_mfma_ws_kernel<1> + sample passes", 5: ("scan_mfma_wide_kernel<1>" if "mfma_shape16=0" in args.option else "scan_mfma_wide16_kernel<1>") + " + sample passes",
-              6: "scan_stream_mfma_kernel<1> + sample passes"}.get(path, f"path {path}")
+    kernel = {0: "scan_topk_kernel", 4: "scan_mfma_ws_kernel<1> + sample passes", 5: "scan_mfma_wide16_kernel<1> + sample passes",
+              6: "scan_stream_lds_kernel<1> + sample passes"}.get(path, f"path {path}")
     if path in (4, 5):
         alg = 2.0 * b * n_local * dim
         roof = {"bound": "mfma", "achieved": alg / (scan_ms * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s"}

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B of one engine option inside ONE process, arms interleaved (boxes differ by +-2 %, runs on one box by ~1 %):
-  python3 benchmarks/ab_option.py --option mfma_shape16 --values 0,1 --batch 1024 [--rows N] [--rounds 6] [--iters 10]
+  python3 benchmarks/ab_option.py --option mfma_skip_sample --values 0,1 --batch 1024 [--rows N] [--rounds 6] [--iters 10]
   python3 benchmarks/ab_option.py --arms "mfma_split_x1000=500,mfma_append_cap=16384;mfma_split_x1000=650,mfma_append_cap=32768" --batch 32"""
 import argparse
 import json

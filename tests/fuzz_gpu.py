@@ -6,7 +6,7 @@
 
 Every case draws a store size that is ragged against the 16-row wave tiles / 256-row protocol tiles / the dense sample,
 a data kind (clustered, isotropic, heavy duplicates = ties, queries that ARE rows), a batch size around the kernel
-families' borders, k / k', and a random setting of the engine's path options (kernel family, MFMA shape, LDS ring,
+families' borders, k / k', and a random setting of the engine's path options (kernel family,
 skip-sample, a tiny append cap that forces the overflow fallback, sharding over repeated device ids), then checks
 ids, distances, order and padding with tests/util.check_topk (tie-tolerant, 1e-5)."""
 import argparse
@@ -50,9 +50,7 @@ def one_case(rng, case):
     opts = {
         "mfma_cost_model": int(rng.integers(0, 2)),
         "mfma_variant": int(rng.choice([4, 5, 6, 6])),
-        "mfma_shape16": int(rng.integers(0, 2)),
         "mfma_skip_sample": int(rng.integers(0, 2)),
-        "stream_lds_ring": int(rng.integers(0, 3)),
         "stream_nt_loads": int(rng.integers(0, 2)),
         "mfma_append_cap": int(rng.choice([256, 1024, 16384, 16384])),
         "mfma_split_x1000": int(rng.choice([250, 500, 650])),

@@ -30,15 +30,13 @@ def corpus33k(oracle_mod):
     return n, dim, spec, rows, queries
 
 
-@pytest.mark.parametrize("lds,nt", [(2, 1), (2, 0), (1, 1), (0, 0), (0, 1)])
-def test_stream_kernel_against_oracle(hip_lib, oracle_mod, corpus33k, lds, nt):
-    """Every query-block count of the streaming kernel (1, 2, 4 blocks of 16) with ragged batches, in both forms
-    (corpus through the per-wave LDS ring — the default — and straight into registers), plain and non-temporal
-    loads; the path taken is asserted, not assumed."""
+@pytest.mark.parametrize("nt", [1, 0])
+def test_stream_kernel_against_oracle(hip_lib, oracle_mod, corpus33k, nt):
+    """Every query-block count of the streaming kernel (1, 2, 4 blocks of 16) with ragged batches, plain and
+    non-temporal loads; the path taken is asserted, not assumed."""
     n, dim, spec, rows, queries = corpus33k
     ix = FlatIndex(dim, "bf16", True)
     ix.set_option("mfma_cost_model", 0)
-    ix.set_option("stream_lds_ring", lds)
     ix.set_option("stream_nt_loads", nt)
     ix.add_synth(0, n, spec)
     qn = _qn(oracle_mod, queries)
@@ -48,7 +46,7 @@ def test_stream_kernel_against_oracle(hip_lib, oracle_mod, corpus33k, lds, nt):
             assert ix.get_stat("last_path") == 6, "the streaming kernel must have served this batch"
             assert ix.get_stat("mfma_last_overflow") == 0
             r_idx, r_dist, r_sc = oracle_mod.exact_topk(rows, queries[:b], k)
-            check_topk(idx, dist, r_idx, r_dist, r_sc, rows, qn[:b], what=f"stream b={b} k={k} lds={lds} nt={nt}")
+            check_topk(idx, dist, r_idx, r_dist, r_sc, rows, qn[:b], what=f"stream b={b} k={k} nt={nt}")
     # the batch-1 GEMV answer is the same answer
     i64, d64 = ix.search(queries, 10, 40)
     for q in (0, 31, 63):
@@ -85,11 +83,9 @@ def test_stream_kernel_multi_pass_and_selfjoin(hip_lib, oracle_mod):
     i6, d6 = ix.search(queries, 10, 40)
     assert np.array_equal(i6, idx) and np.array_equal(d6, dist)
     ix.set_option("mfma_skip_sample", 1)
-    ix.set_option("stream_lds_ring", 0)         # the register form multiplies in the same order: same bits
-    ix.set_option("stream_nt_loads", 0)
+    ix.set_option("stream_nt_loads", 0)         # plain loads: same bits
     i7, d7 = ix.search(queries, 10, 40)
     assert ix.get_stat("last_path") == 6 and np.array_equal(i7, idx) and np.array_equal(d7, dist)
-    ix.set_option("stream_lds_ring", 2)
     ix.set_option("stream_nt_loads", 1)
     sj_idx, sj_dist = ix.selfjoin(5, exclude_self=True, rerank_kprime=40, q_row0=299_950, q_n=57)
     assert ix.get_stat("last_path") == 6
@@ -127,9 +123,9 @@ def test_stream_kernel_overflow_fallback_and_bad_thresholds(hip_lib, oracle_mod,
     ix.close()
 
 
-def test_wide_kernel_mfma_shapes_agree(hip_lib, oracle_mod):
-    """The wide tile on v_mfma_f32_16x16x32_bf16 (default) and on 32x32x16: same candidates, so the same ids and
-    distances bit for bit — several corpus tiles per block, ragged last corpus tile, ragged query tile, self-join
+def test_wide_kernel_against_the_other_families(hip_lib, oracle_mod):
+    """The wide tile (256 x 256 on v_mfma_f32_16x16x32_bf16) against the 128-wide kernel: same candidates, so the same ids
+    and distances bit for bit — several corpus tiles per block, ragged last corpus tile, ragged query tile, self-join
     exclusion, and the oracle's answer."""
     n, dim, b = 140_003, 768, 450
     spec = SynthSpec(seed=271, kind=1, n_clusters=374, noise=0.3)
@@ -143,11 +139,12 @@ def test_wide_kernel_mfma_shapes_agree(hip_lib, oracle_mod):
     i16, d16 = ix.search(queries, 10, 40)
     assert ix.get_stat("last_path") == 5 and ix.get_stat("mfma_last_overflow") == 0
     sj16 = ix.selfjoin(5, exclude_self=True, rerank_kprime=40, q_row0=n - 300, q_n=300)
-    ix.set_option("mfma_shape16", 0)
-    i32, d32 = ix.search(queries, 10, 40)
-    sj32 = ix.selfjoin(5, exclude_self=True, rerank_kprime=40, q_row0=n - 300, q_n=300)
-    assert np.array_equal(i16, i32) and np.array_equal(d16, d32)
-    assert np.array_equal(sj16[0], sj32[0]) and np.array_equal(sj16[1], sj32[1])
+    ix.set_option("mfma_variant", 4)
+    i4, d4 = ix.search(queries, 10, 40)
+    assert ix.get_stat("last_path") == 4
+    sj4 = ix.selfjoin(5, exclude_self=True, rerank_kprime=40, q_row0=n - 300, q_n=300)
+    assert np.array_equal(i16, i4) and np.array_equal(d16, d4)
+    assert np.array_equal(sj16[0], sj4[0]) and np.array_equal(sj16[1], sj4[1])
     assert not np.any(sj16[0] == (n - 300 + np.arange(300))[:, None])
     r_idx, r_dist, r_sc = oracle_mod.exact_topk(rows, queries[:64], 10)
     check_topk(i16[:64], d16[:64], r_idx, r_dist, r_sc, rows, _qn(oracle_mod, queries[:64]), what="wide 16x16x32")

@@ -53,7 +53,6 @@ MfPlan mfma_plan(int b, int n_rows, int n_cu, int variant_opt) {
 hipError_t mfma_prepare_device() {
   MF_TRY(hipFuncSetAttribute((const void*)scan_mfma_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_smem_bytes()));
   MF_TRY(ws_prepare_device());
-  MF_TRY(wide_prepare_device());
   MF_TRY(wide16_prepare_device());
   MF_TRY(stream_prepare());
   return hipSuccess;
@@ -86,8 +85,8 @@ hipError_t mfma_search_launch(const MfSearchArgs& a, int* skipped_tiles) {
     p.pass_tiles = (int)pass_tiles; p.stride = stride; p.skip_n = skip_n; p.self0 = self0;
     p.thr = thr; p.dense = dense; p.cand_cnt = cand_cnt; p.cand_s = cand_s; p.cand_i = cand_i; p.cap = cap;
     p.ovf = ovf; p.ablate = a.ablate; p.st = st;
-    if (variant == 6) return stream_pass(p, a.n_cu, a.stream_nt, a.stream_blocks_per_cu, a.stream_lds);
-    if (variant == 5) return a.shape16 ? wide16_launch_pass(p) : wide_launch_pass(p);
+    if (variant == 6) return stream_pass(p, a.n_cu, a.stream_nt);
+    if (variant == 5) return wide16_launch_pass(p);
     return ws_launch_pass(p);
   };
 

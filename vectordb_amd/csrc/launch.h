@@ -1,6 +1,6 @@
 // launch.h — host-side seams between the translation units of libvdb_hip.so.
 // The kernels are heavy template families (72 GEMV-scan instantiations, the MFMA pass kernels);
-// each family compiles in its own TU (k_gemv.hip; k_mfma.hip and, behind mfma_pass.h, k_mfma_ws/_wide/_wide16.hip, k_stream.hip) so that the library
+// each family compiles in its own TU (k_gemv.hip; k_mfma.hip and, behind mfma_pass.h, k_mfma_ws/_wide16.hip, k_stream.hip) so that the library
 // builds in parallel and a change to one kernel rebuilds one file.  vdb_api.hip (the C ABI and all
 // orchestration) sees only these plain functions.  No device symbol crosses a TU.
 #pragma once
@@ -27,7 +27,7 @@ bool launch_scan_any(bool bf16, const ScanArgs& a, int ld, int e, bool nt);
 struct MfSearchArgs {
   const unsigned char* rows_bf16; int n_rows; const float* qn; int b; int kk; int self0;
   int n_cu; int variant;           // 4 = 256x128 warp-specialised, 5 = 256x256 wide tile, 6 = streaming (<= 64 queries)
-  int cap; int split_x1000; int skip_sample; int force_fallback; int ablate; int stream_nt; int stream_blocks_per_cu; int shape16; int stream_lds;
+  int cap; int split_x1000; int skip_sample; int force_fallback; int ablate; int stream_nt;
   unsigned char* qb16;             // [b_pad][768] bf16
   float* cand_s; int* cand_i;      // [b][cap]
   int* cand_cnt;                   // [b] counters, kMfCntStrideC ints apart, + the overflow flag behind them

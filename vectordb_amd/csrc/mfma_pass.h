@@ -1,5 +1,5 @@
 // mfma_pass.h — host-side seam between k_mfma.hip (the batched search's orchestration, selection and fallback kernels)
-// and the pass-kernel families, each of which instantiates in its own translation unit (k_mfma_ws.hip, k_mfma_wide.hip,
+// and the pass-kernel families, each of which instantiates in its own translation unit (k_mfma_ws.hip,
 // k_mfma_wide16.hip, k_stream.hip): the library builds in parallel and a change to one kernel rebuilds one file.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -18,10 +18,9 @@ constexpr int kM5BNC = 256;     // queries per block of the wide tile (scan_mfma
 constexpr int kStMaxBC = 64;    // queries the streaming kernel serves at most (scan_stream.h asserts it)
 
 hipError_t ws_prepare_device();       hipError_t ws_launch_pass(const MfPassArgs& p);        // scan_mfma4.h: 256 x 128, warp-specialised
-hipError_t wide_prepare_device();     hipError_t wide_launch_pass(const MfPassArgs& p);      // scan_mfma5.h: 256 x 256 on 32x32x16
-hipError_t wide16_prepare_device();   hipError_t wide16_launch_pass(const MfPassArgs& p);    // scan_mfma6.h: 256 x 256 on 16x16x32
+hipError_t wide16_prepare_device();   hipError_t wide16_launch_pass(const MfPassArgs& p);    // scan_mfma5.h / scan_mfma6.h: 256 x 256
 // scan_stream.h: <= 64 queries, corpus straight from HBM (the grid is the kernel's own: n_qt/n_splits/xcd_map unused)
 hipError_t stream_prepare();
-hipError_t stream_pass(const MfPassArgs& p, int n_cu, int nt, int blocks_per_cu, int lds_ring);
+hipError_t stream_pass(const MfPassArgs& p, int n_cu, int nt);
 
 }  // namespace vdbk

@@ -1,32 +1,32 @@
-// scan_stream.h — pass kernel of the batched bf16 path for SMALL batches (2..64 queries): the corpus
-// goes from HBM straight into MFMA fragments.
+// scan_stream.h — pass kernel of the batched bf16 path for SMALL batches (3..64 queries): HBM-bound, one corpus pass serves
+// the whole batch.
 //
-// Why: a batch of 2..64 queries is as HBM-bound as one query (intensity <= 64 flop/B against a ridge of
-// 312), but the GEMV scan (scan_gemv.h) pays FMAs and a wave reduction per query (4 queries per pass cost
-// 1.64x one), and the tiled MFMA kernels (scan_mfma4.h/5.h) stage the corpus through LDS for a reuse that
-// a single query tile does not have.  Here nothing of the corpus touches LDS:
-//   * a wave owns 16 corpus rows at a time.  v_mfma_f32_16x16x32_bf16 wants, as its A operand, lane l to
-//     hold 8 consecutive K-values (16 bytes) of row l%16 at K-chunk l/16 — which is exactly a
-//     global_load_dwordx4 of row l%16, byte offset s*64 + (l/16)*16, for K-step s: 24 such loads cover a
-//     row's 1536 bytes, each a 1 KiB wave-instruction made of sixteen 64-byte row pieces (two
-//     wave-instructions consume each 128-byte line), and each feeds NQ MFMAs (16 queries each);
-//   * the (<= 64) queries live in LDS for the whole kernel as the B operand, rows padded to 1552 bytes so
-//     that the 16 lanes of a ds_read_b128 phase hit 16 different bank groups;
-//   * 12 loads (12 KiB) stay in flight per wave across tile boundaries (register ring, compile-time
-//     slots); no barrier after the query image is in place — waves are independent;
-//   * the epilogue is the protocol's (scan_mfma3.h): MODE 0 writes the dense sample's scores, MODE 1
-//     appends rows scoring >= the query's threshold to its candidate buffer.  A lane holds 4 scores of one
-//     query per 16-query block: an integer max tree + one ballot decide the common (no hit) case; the
-//     atomics of a tile with hits are issued together and waited for once.
-// The work unit is a 16-row slice of one of the protocol's 256-row tiles, dealt round-robin to the waves
-// of the grid, so that the chip walks the corpus as one contiguous window (like the GEMV scan).
-// Algorithmic bytes per final pass = n_rows * 1536: the kernel is priced against the HBM roofline.
+// Why: a batch of up to 64 queries is as HBM-bound as one query (intensity <= 64 flop/B against a ridge of 312), but the
+// GEMV scan (scan_gemv.h) pays FMAs and a wave reduction per query (4 queries per pass cost 1.64x one), and the tiled MFMA
+// kernels (scan_mfma4.h/6.h) stage the corpus through block-shared LDS tiles for a reuse one query tile does not have.
+//   * a wave owns 16 corpus rows at a time and multiplies them with v_mfma_f32_16x16x32_bf16 (A = 16 rows x 32 K) against
+//     NQ blocks of 16 queries;
+//   * the (<= 64) queries live in LDS for the whole kernel as the B operand, rows padded to 1552 bytes so that the 16
+//     lanes of a ds_read_b128 phase hit 16 different bank groups; an opaque offset keeps hipcc from hoisting the
+//     loop-invariant fragment reads into 96 NQ registers;
+//   * the corpus comes in WHOLE cache lines: a wave brings its 16 rows in slabs of 16 x 128 bytes = two coalesced LDS-DMA
+//     instructions (global_load_lds_dwordx4: 8 lanes per row-line, 8 rows per instruction, no VGPR round trip) into a
+//     PRIVATE ring of slabs and reads the A fragments back in MFMA layout with ds_read_b128.  LDS position (16-byte units)
+//     of (row m, chunk ch) inside a slab: m*8 + (ch ^ ((m>>1)&7)) — the swizzle is applied on the SOURCE address of each DMA
+//     lane and makes the 16 lanes of a fragment read fall into 16 different bank groups.  No barrier after the query image
+//     is in place: a wave only ever reads what its own DMA wrote, behind a counted s_waitcnt vmcnt (the younger slabs of
+//     the ring stay in flight);
+//   * the epilogue is the protocol's (scan_mfma3.h): MODE 0 writes the dense sample's scores, MODE 1 appends rows scoring
+//     >= the query's threshold to its candidate buffer.  A lane holds 4 scores of one query per 16-query block: an integer
+//     max tree + one ballot decide the common (no hit) case; hits wait in registers and reserve their slots together.
+// The work unit is a 16-row slice of one of the protocol's 256-row tiles, dealt round-robin to the waves of the grid, so
+// that the chip walks the corpus as one contiguous window (like the GEMV scan).
+// Algorithmic bytes per final pass = n_rows * 1536: the kernel is priced against the HBM roofline (6.6-6.7 TB/s measured).
 //
-// Two forms.  scan_stream_kernel (this one, "register form"): fragments straight from global_load_dwordx4 — no LDS
-// for the corpus at all, but its 64-byte row pieces are HALF cache lines, which the memory path delivers ~13 %
-// slower (6.1 TB/s in the final pass at 10M rows).  scan_stream_lds_kernel (below, the default for the append
-// passes): whole lines by LDS-DMA into a per-wave ring, fragments read back transposed — 6.6-6.8 TB/s; measured per
-// step at 10M rows: 2.47 ms (B = 4), 2.50 (16), 2.48-2.58 (32), 2.42-2.49 (64) against 2.66-2.73 for the register form.
+// History: the first form fed the MFMAs straight from global_load_dwordx4 (lane l = row l%16, K-chunk l/16: exactly the A
+// fragment, no LDS for the corpus at all).  Its 64-byte row pieces are HALF cache lines, which the memory path delivers
+// ~13 % slower: 2.66-2.73 ms per step at 10M rows against 2.36-2.39 for this one (profiles/r02_batch_sweep_forced.txt); it
+// was retired once this form also served the dense pass.
 #pragma once
 #include "scan_mfma3.h"
 
@@ -41,160 +41,9 @@ constexpr int kStWaves = kStThreads / 64;
 constexpr int kStQStride = kMfRowBytes + 16;     // LDS row stride of a query: 1552 B (1536 + one 16-byte bank-group shift)
 constexpr int kStRows = 16;                      // corpus rows per wave tile (M of the MFMA)
 constexpr int kStSub = kMfBM / kStRows;          // wave tiles per 256-row protocol tile
-constexpr int kStSteps = kMfRowBytes / 64;       // 24 K-steps of 32
-constexpr int kStRing = 12;                      // loads in flight per lane (1 KiB per wave each)
-static_assert(kStSteps == 2 * kStRing, "a tile is two half-tiles of kStRing steps");
 
 __host__ __device__ constexpr size_t st_smem_bytes(int nq) { return (size_t)nq * 16 * kStQStride; }
 
-template <bool NT>
-__device__ __forceinline__ st_u32x4 st_load(const unsigned char* p) {
-  if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const st_u32x4*>(p));
-  else return *reinterpret_cast<const st_u32x4*>(p);
-}
-
-template <int MODE, int NQ, bool NT>   // NQ 16-query blocks (1, 2 or 4)
-__global__ __launch_bounds__(kStThreads, (NQ <= 2 ? 4 : 2)) void scan_stream_kernel(   // HIP: 2nd = min waves per SIMD
-    const unsigned char* __restrict__ rows, int n_rows, const unsigned char* __restrict__ qb16, int b,
-    int n_pass_tiles, int tile_stride, int skip_n, int self0, const float* __restrict__ thr_in,
-    float* __restrict__ dense, int* __restrict__ cand_cnt, float* __restrict__ cand_s, int* __restrict__ cand_i, int cap) {
-  extern __shared__ __align__(16) unsigned char smem[];   // the query image: NQ*16 rows of kStQStride bytes
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int w = tid >> 6;
-  const int m = lane & 15;      // A: corpus row of the tile / B, C: query of the block
-  const int c = lane >> 4;      // K-chunk of a step (A, B) / row group of C
-
-  for (int i = tid; i < NQ * 16 * (kMfRowBytes / 16); i += kStThreads) {
-    const int qr = i / (kMfRowBytes / 16), ch = i - qr * (kMfRowBytes / 16);
-    *reinterpret_cast<st_u32x4*>(smem + qr * kStQStride + ch * 16) =
-        *reinterpret_cast<const st_u32x4*>(qb16 + (size_t)qr * kMfRowBytes + ch * 16);
-  }
-  __syncthreads();   // the only barrier
-
-  float thr[NQ];
-  int thr_bits[NQ];   // integer-compare form of the threshold (scan_mfma5.h): exact for positive thresholds, always-pass otherwise
-#pragma unroll
-  for (int nq = 0; nq < NQ; ++nq) {
-    thr[nq] = (MODE == 1 && thr_in) ? thr_in[min(nq * 16 + m, b - 1)] : -INFINITY;
-    thr_bits[nq] = thr[nq] > 0.f ? __float_as_int(thr[nq]) : (int)0x80000000;
-  }
-
-  const long long n_units = (long long)n_pass_tiles * kStSub;
-  const long long nw = (long long)gridDim.x * kStWaves;
-  long long u = (long long)blockIdx.x * kStWaves + w;
-  if (u >= n_units) return;
-  auto unit_row0 = [&](long long uu) -> int {
-    const int t = (int)(uu / kStSub), sub = (int)(uu - (long long)t * kStSub);
-    return pass_tile(t, tile_stride, skip_n) * kMfBM + sub * kStRows;
-  };
-  auto lane_ptr = [&](int row0) -> const unsigned char* { return rows + ((size_t)row0 + m) * kMfRowBytes + c * 16; };
-  const unsigned char* qfrag = smem + m * kStQStride + c * 16;
-
-  int row0 = unit_row0(u);
-  const unsigned char* pc = lane_ptr(row0);
-  st_u32x4 buf[kStRing];
-#pragma unroll
-  for (int s = 0; s < kStRing; ++s) buf[s] = st_load<NT>(pc + s * 64);
-
-  for (;;) {
-    const long long un = u + nw;
-    const bool has_next = un < n_units;
-    const int row0n = has_next ? unit_row0(un) : row0;   // the last unit refills from itself: harmless, never consumed
-    const unsigned char* pn = lane_ptr(row0n);
-    f32x4_t acc[NQ];
-#pragma unroll
-    for (int nq = 0; nq < NQ; ++nq) acc[nq] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    // The query fragments are loop-invariant, and hipcc would hoist all 24*NQ ds_read_b128 out of the tile loop
-    // (96*NQ registers: spills from NQ = 2 on).  An offset it cannot see through keeps them where they are.
-    int qoff = 0;
-    asm volatile("" : "+v"(qoff));
-    // a tile = two half-tiles of kStRing steps; slot s is consumed at step s of a half and refilled at once with
-    // step s of the NEXT half (of this tile, then of the next tile).  The halves are a real loop so that the ring
-    // is 12 x 4 registers (unrolled over the whole tile hipcc names 24 buffers and spills at 4 waves per SIMD).
-#pragma unroll 1
-    for (int half = 0; half < 2; ++half) {
-      const unsigned char* refill = half == 0 ? pc + kStRing * 64 : pn;
-      const unsigned char* qh = qfrag + qoff + half * (kStRing * 64);
-      bf16x8_t qf[2][NQ];   // query fragments of this step and the next (their LDS latency hides behind the MFMAs)
-#pragma unroll
-      for (int nq = 0; nq < NQ; ++nq) qf[0][nq] = *reinterpret_cast<const bf16x8_t*>(qh + nq * 16 * kStQStride);
-#pragma unroll
-      for (int s = 0; s < kStRing; ++s) {
-        if (s + 1 < kStRing) {
-#pragma unroll
-          for (int nq = 0; nq < NQ; ++nq)
-            qf[(s + 1) & 1][nq] = *reinterpret_cast<const bf16x8_t*>(qh + nq * 16 * kStQStride + (s + 1) * 64);
-        }
-        const bf16x8_t a = __builtin_bit_cast(bf16x8_t, buf[s]);
-#pragma unroll
-        for (int nq = 0; nq < NQ; ++nq) acc[nq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[s & 1][nq], acc[nq], 0, 0, 0);
-        buf[s] = st_load<NT>(refill + s * 64);
-        // pin the step: left alone, hipcc delays the refills until it wants the registers and the wave runs with
-        // 3-5 loads in flight instead of 12
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-
-    // ---- epilogue: C[row 4c+reg of the tile][query m of block nq] ----
-    const int t_local = (int)(u / kStSub), sub = (int)(u - (long long)t_local * kStSub);
-    if (MODE == 0) {
-#pragma unroll
-      for (int nq = 0; nq < NQ; ++nq) {
-        const int qg = nq * 16 + m;
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const int rloc = sub * kStRows + 4 * c + reg;
-          const int row = row0 + 4 * c + reg;
-          const bool ok = (row < n_rows) && !(self0 >= 0 && row == self0 + qg);
-          if (qg < b) dense[(size_t)qg * kMf3DenseLd + t_local * kMfBM + rloc] = ok ? acc[nq][reg] : -INFINITY;
-        }
-      }
-    } else {
-      bool any = false;
-#pragma unroll
-      for (int nq = 0; nq < NQ; ++nq) {
-        const int mx = max(max(__float_as_int(acc[nq][0]), __float_as_int(acc[nq][1])),
-                           max(__float_as_int(acc[nq][2]), __float_as_int(acc[nq][3])));
-        any = any || (mx >= thr_bits[nq]);
-      }
-      if (__ballot(any) != 0ull) {   // rare in the final pass (hits are ~2e-4 of its scores)
-        int pos[NQ][4];
-#pragma unroll
-        for (int nq = 0; nq < NQ; ++nq) {
-          const int qg = nq * 16 + m;
-#pragma unroll
-          for (int reg = 0; reg < 4; ++reg) {
-            const int row = row0 + 4 * c + reg;
-            const bool pass = (acc[nq][reg] >= thr[nq]) && (row < n_rows) && (qg < b) && !(self0 >= 0 && row == self0 + qg);
-            pos[nq][reg] = pass ? atomicAdd(&cand_cnt[qg * kMfCntStride], 1) : cap;   // all in flight, one wait
-          }
-        }
-#pragma unroll
-        for (int nq = 0; nq < NQ; ++nq) {
-          const int qg = nq * 16 + m;
-#pragma unroll
-          for (int reg = 0; reg < 4; ++reg)
-            if (pos[nq][reg] < cap) {
-              cand_s[(size_t)qg * cap + pos[nq][reg]] = acc[nq][reg];
-              cand_i[(size_t)qg * cap + pos[nq][reg]] = row0 + 4 * c + reg;
-            }
-        }
-      }
-    }
-    if (!has_next) break;
-    u = un; row0 = row0n; pc = pn;
-  }
-}
-
-// ---- the same kernel with the corpus transposed through a per-wave LDS ring (whole cache lines) ----------------
-// The register form above reads 64-byte row pieces: half cache lines, which the memory path delivers ~13 % slower than
-// whole ones.  Here a wave brings its 16 rows in slabs of 16 x 128 bytes = two coalesced LDS-DMA instructions
-// (global_load_lds_dwordx4: 8 lanes per row-line, 8 rows per instruction, no VGPR round trip) into a private ring of
-// kStSlabs slabs, and reads the A fragments back in MFMA layout with ds_read_b128.  LDS position (16-byte units) of
-// (row m, chunk ch) inside a slab: m*8 + (ch ^ ((m>>1)&7)) — the swizzle is applied on the SOURCE address of each DMA
-// lane, and makes the 16 lanes of a fragment read fall into 16 different bank groups.  No barrier: a wave only ever
-// reads what its own DMA wrote, behind a counted s_waitcnt vmcnt (the younger slabs of the ring stay in flight).
 constexpr int kStSlabBytes = kStRows * 128;          // 2 KiB: 16 rows x one 128-byte line = two k32 steps
 constexpr int kStSlabsPerTile = kMfRowBytes / 128;   // 12
 // ring depth per wave: 6 slabs (12 KiB, 10 KiB in flight) beside <= 32 queries; 3 beside 33..64 (their image takes 97 KiB)
@@ -378,11 +227,8 @@ inline int st_blocks(int b) { const int nq = (b + 15) / 16; return nq <= 1 ? 1 :
 inline hipError_t stream_prepare_device() {
   hipError_t e;
 #define ST_ATTR(MODE, NQ, NT) \
-  if ((e = hipFuncSetAttribute((const void*)scan_stream_kernel<MODE, NQ, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)st_smem_bytes(NQ))) != hipSuccess) return e;
-  ST_ATTR(0, 4, false) ST_ATTR(1, 4, false) ST_ATTR(1, 4, true)
-#undef ST_ATTR
-#define ST_ATTR(MODE, NQ, NT) \
   if ((e = hipFuncSetAttribute((const void*)scan_stream_lds_kernel<MODE, NQ, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)st_lds_smem_bytes(NQ))) != hipSuccess) return e;
+  ST_ATTR(0, 1, false) ST_ATTR(0, 2, false) ST_ATTR(0, 4, false)
   ST_ATTR(1, 1, false) ST_ATTR(1, 1, true) ST_ATTR(1, 2, false) ST_ATTR(1, 2, true) ST_ATTR(1, 4, false) ST_ATTR(1, 4, true)
 #undef ST_ATTR
   return hipSuccess;
@@ -391,33 +237,21 @@ inline hipError_t stream_prepare_device() {
 // one pass over n_pass_tiles protocol tiles (pass_tile(i, stride, skip_n)); mode 0 = dense sample, 1 = append
 inline void stream_launch_pass(int mode, const unsigned char* rows, int n_rows, const unsigned char* qb16, int b, int n_pass_tiles,
                                int tile_stride, int skip_n, int self0, const float* thr, float* dense, int* cand_cnt,
-                               float* cand_s, int* cand_i, int cap, int n_cu, int nt, int blocks_per_cu, int lds_ring, hipStream_t st) {
+                               float* cand_s, int* cand_i, int cap, int n_cu, int nt, hipStream_t st) {
   const int nq = st_blocks(b);
   const long long units = (long long)n_pass_tiles * kStSub;
-  if (lds_ring && mode == 1 && (nq <= 2 || lds_ring >= 2)) {   // append passes: whole cache lines through the per-wave LDS ring
-    const int grid = (int)std::max<long long>(1, std::min<long long>((long long)n_cu, (units + kStWaves - 1) / kStWaves));
-#define STL_LAUNCH(NQ, NT)                                                                                                          \
-  hipLaunchKernelGGL((scan_stream_lds_kernel<1, NQ, NT>), dim3(grid), dim3(kStThreads), st_lds_smem_bytes(NQ), st, rows, n_rows, qb16, b, \
-                     n_pass_tiles, tile_stride, skip_n, self0, thr, dense, cand_cnt, cand_s, cand_i, cap)
-    if (nq == 1) { if (nt) STL_LAUNCH(1, true); else STL_LAUNCH(1, false); }
-    else if (nq == 2) { if (nt) STL_LAUNCH(2, true); else STL_LAUNCH(2, false); }
-    else { if (nt) STL_LAUNCH(4, true); else STL_LAUNCH(4, false); }
-#undef STL_LAUNCH
-    return;
-  }
-  const int per_cu = blocks_per_cu > 0 ? blocks_per_cu : (nq <= 2 ? 2 : 1);
-  const int grid = (int)std::max<long long>(1, std::min<long long>((long long)n_cu * per_cu, (units + kStWaves - 1) / kStWaves));
-#define ST_LAUNCH(MODE, NQ, NT)                                                                                                   \
-  hipLaunchKernelGGL((scan_stream_kernel<MODE, NQ, NT>), dim3(grid), dim3(kStThreads), st_smem_bytes(NQ), st, rows, n_rows, qb16, b, \
+  const int grid = (int)std::max<long long>(1, std::min<long long>((long long)n_cu, (units + kStWaves - 1) / kStWaves));   // one block per CU
+#define STL_LAUNCH(MODE, NQ, NT)                                                                                                       \
+  hipLaunchKernelGGL((scan_stream_lds_kernel<MODE, NQ, NT>), dim3(grid), dim3(kStThreads), st_lds_smem_bytes(NQ), st, rows, n_rows, qb16, b, \
                      n_pass_tiles, tile_stride, skip_n, self0, thr, dense, cand_cnt, cand_s, cand_i, cap)
   if (mode == 0) {
-    if (nq == 1) ST_LAUNCH(0, 1, false); else if (nq == 2) ST_LAUNCH(0, 2, false); else ST_LAUNCH(0, 4, false);
+    if (nq == 1) STL_LAUNCH(0, 1, false); else if (nq == 2) STL_LAUNCH(0, 2, false); else STL_LAUNCH(0, 4, false);
   } else if (nt) {
-    if (nq == 1) ST_LAUNCH(1, 1, true); else if (nq == 2) ST_LAUNCH(1, 2, true); else ST_LAUNCH(1, 4, true);
+    if (nq == 1) STL_LAUNCH(1, 1, true); else if (nq == 2) STL_LAUNCH(1, 2, true); else STL_LAUNCH(1, 4, true);
   } else {
-    if (nq == 1) ST_LAUNCH(1, 1, false); else if (nq == 2) ST_LAUNCH(1, 2, false); else ST_LAUNCH(1, 4, false);
+    if (nq == 1) STL_LAUNCH(1, 1, false); else if (nq == 2) STL_LAUNCH(1, 2, false); else STL_LAUNCH(1, 4, false);
   }
-#undef ST_LAUNCH
+#undef STL_LAUNCH
 }
 
 }  // namespace vdbk

@@ -79,10 +79,7 @@ struct vdb {
   bool mfma_attr_set = false;    // dynamic-LDS limits of the MFMA kernels raised on this handle's device
   int mfma_cost_model = 1;       // 0: every supported batch >= batch_mfma_min_b takes the MFMA path (tests)
   int mfma_ablate = 0;   // diagnostic: skip parts of the MFMA kernel (wrong results, timing only)
-  int stream_nt = 1;     // the streaming kernel's append passes: 1 = non-temporal corpus loads (right for the LDS ring: whole lines, read once; wrong for the register form's half lines)
-  int stream_blocks_per_cu = 0;   // 0 = the kernel's own choice
-  int stream_lds = 2;             // the streaming kernel's append passes through the per-wave LDS ring (whole cache lines): 0 = never (register form), 1 = up to 32 queries, 2 = always
-  int mfma_shape16 = 1;           // the wide-tile kernel on v_mfma_f32_16x16x32_bf16 (scan_mfma6.h; 1.3-1.9 % faster, interleaved A/B) instead of 32x32x16 (scan_mfma5.h)
+  int stream_nt = 1;     // the streaming kernel's append passes: non-temporal corpus loads (whole lines, read once)
   // workspaces (grown on demand)
   DevBuf w_q, w_part_s, w_part_i, w_part2_s, w_part2_i, w_stage, w_out_i, w_out_d, w_idx, w_mfma;
   DevBuf w_q1, w_part_s1, w_part_i1, w_part2_s1, w_part2_i1;   // second set: slot 1 of the two-phase search
@@ -323,7 +320,7 @@ int mfma_search(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
   a.rows_bf16 = (const unsigned char*)h->rows_bf16; a.n_rows = n_rows; a.qn = qn; a.b = b; a.kk = kk;
   a.self0 = self_row0 >= 0 ? (int)self_row0 : -1;
   a.n_cu = h->n_cu; a.variant = h->mfma_variant; a.cap = cap; a.split_x1000 = h->mfma_split_x1000 ? h->mfma_split_x1000 : (pl.variant == 6 ? 600 : 500);
-  a.skip_sample = h->mfma_skip_sample; a.force_fallback = h->mfma_force_fallback; a.ablate = h->mfma_ablate; a.stream_nt = h->stream_nt; a.stream_blocks_per_cu = h->stream_blocks_per_cu; a.shape16 = h->mfma_shape16; a.stream_lds = h->stream_lds;
+  a.skip_sample = h->mfma_skip_sample; a.force_fallback = h->mfma_force_fallback; a.ablate = h->mfma_ablate; a.stream_nt = h->stream_nt;
   a.qb16 = (unsigned char*)h->w_mfma.p;
   a.cand_s = (float*)h->w_cand_s.p; a.cand_i = (int*)h->w_cand_i.p; a.cand_cnt = (int*)h->w_cand_cnt.p;
   a.thr = (float*)h->w_thr.p; a.dense = (float*)h->w_dense.p;
@@ -1373,9 +1370,6 @@ int vdb_set_option(vdb_t* h, const char* name, int64_t value) {
   }
   if (!strcmp(name, "scan_nt_loads")) { h->scan_nt_loads = value != 0; return VDB_OK; }
   if (!strcmp(name, "stream_nt_loads")) { h->stream_nt = value != 0; return VDB_OK; }
-  if (!strcmp(name, "mfma_shape16")) { h->mfma_shape16 = value != 0; return VDB_OK; }
-  if (!strcmp(name, "stream_lds_ring")) { if (value < 0 || value > 2) return fail(h, VDB_ERR_ARG, "stream_lds_ring must be 0, 1 (<= 32 queries) or 2 (<= 64)"); h->stream_lds = (int)value; return VDB_OK; }
-  if (!strcmp(name, "stream_blocks_per_cu")) { if (value < 0 || value > 8) return fail(h, VDB_ERR_ARG, "stream_blocks_per_cu must be in [0,8]"); h->stream_blocks_per_cu = (int)value; return VDB_OK; }
   if (!strcmp(name, "mfma_ablate")) { h->mfma_ablate = (int)value; return VDB_OK; }
   if (!strcmp(name, "mfma_variant")) {
     if (value < 4 || value > 6) return fail(h, VDB_ERR_ARG, "mfma_variant must be 4, 5 or 6");
