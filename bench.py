@@ -324,7 +324,12 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         self_launch(args)                      # does not return
     traffic, traffic_note = None, "not collected (--no-traffic-pass, or more than one rank)"
-    if world == 1 and not args.no_traffic_pass:
+    profiled = any(k.startswith(("ROCP", "ROCPROF")) for k in os.environ) or "HSA_TOOLS_LIB" in os.environ or \
+        "rocprof" in os.environ.get("LD_PRELOAD", "")
+    if profiled:
+        # under a profiler this process may already hold the GPU (its preloaded tool initialises it): no child processes then
+        traffic_note = "not collected: this run is itself under a profiler"
+    elif world == 1 and not args.no_traffic_pass:
         traffic, traffic_note = traffic_pass(args)          # a child process; nothing here has touched the GPU yet
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
