@@ -286,7 +286,9 @@ def measure(sh, args, b, steps, warmup, qspec, device, world, n_local):
     # bare bf16 MFMA loop)
     try:
         if roof["bound"] == "mfma":
-            roof["measured_peak"] = sh.local.get_stat("probe_mfma_bf16_gflops") / 1e3
+            # bare MFMA loops on RANDOM operands, every CU busy: the shape the pass kernel is built on, and the other one
+            roof["measured_peak"] = sh.local.get_stat("probe_mfma16_bf16_gflops") / 1e3
+            roof["measured_peak_other_shape_32x32x16"] = sh.local.get_stat("probe_mfma_bf16_gflops") / 1e3
         else:
             roof["measured_peak"] = sh.local.get_stat("probe_hbm_read_mbps") / 1e3
         roof["frac_of_measured_peak"] = roof["achieved"] / roof["measured_peak"] if roof["measured_peak"] else None

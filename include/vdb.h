@@ -253,7 +253,9 @@ int vdb_timing_stats(vdb_t* h, int64_t* n_searches, double* scan_ms_sum, double*
  * 0: whenever it is supported), "mfma_variant" (4: 256x128 tiles only; 5: + 256x256 tiles; 6, default: + the streaming
  * kernel for <= 64 queries), "stream_nt_loads", "mfma_append_cap", "mfma_split_x1000" (where the sample pass sits between the dense sample and
  * the full pass: 0, the default, = 500, the geometric mean, for the tiled kernels and 600 for the streaming kernel, both measured
- * best; or 100..900), "mfma_force_fallback".
+ * best; or 100..900), "mfma_skip_sample" (default 1: the last of two append passes leaves out the tiles the sample pass
+ * multiplied), "mfma_force_fallback" (test hook: the exact list kernel serves the batch), "mfma_ablate" (diagnostic builds of the
+ * pass kernels; bits 1, 2, 4, 8 give INVALID results — timing only; bit 128 = one append flush per hit).
  * Unknown names return VDB_ERR_ARG. */
 int vdb_set_option(vdb_t* h, const char* name, int64_t value);
 
@@ -265,7 +267,8 @@ int vdb_set_option(vdb_t* h, const char* name, int64_t value);
  * "mfma_last_hits", "mfma_last_skipped_tiles" (tiles the final pass of the last
  * batched search left out because the sample pass had multiplied them); measured ceilings of this device (a few ms
  * each): "probe_hbm_read_mbps" (streams the store's own rows, needs >= 64 MiB of them) and
- * "probe_mfma_bf16_gflops" (bare v_mfma_f32_32x32x16_bf16 loop).  Unknown names return VDB_ERR_ARG. */
+ * "probe_mfma16_bf16_gflops" / "probe_mfma_bf16_gflops" (bare v_mfma_f32_16x16x32_bf16 / 32x32x16 loops on random operands).
+ * Unknown names return VDB_ERR_ARG. */
 int vdb_get_stat(vdb_t* h, const char* name, int64_t* value);
 
 /* ---- synthetic data (bench/test utility; no reference counterpart) ----- */
