@@ -425,6 +425,11 @@ def test_batched_search_on_a_store_without_the_fp32_copy(hip_lib, oracle_mod, co
         assert np.allclose(dist, d0[:b], atol=1e-6)
     sj_i, sj_d = ix.selfjoin(5, exclude_self=True, rerank_kprime=40, q_row0=100, q_n=70)
     assert not np.any(sj_i == (100 + np.arange(70))[:, None]) and np.all(np.diff(sj_d, axis=1) >= 0)
+    # k' > 64: the generic finish (merge_lists_kernel + rerank_kernel) re-scores against the bf16 rows as well
+    r30 = oracle_mod.exact_topk(src, queries[:5], 30)
+    i30, d30 = ix.search(queries[:5], 30, 200)
+    assert ix.get_stat("last_path") == 0
+    check_topk(i30, d30, r30[0], r30[1], r30[2], src, qn[:5], what="bf16-only k=30 k'=200")
     ix.close()
     sh = FlatIndex(dim, "bf16", False, devices=[0, 0, 0])
     sh.set_option("mfma_cost_model", 0)
