@@ -122,11 +122,12 @@ def gemv_case(rng, case):
     if n > 5:
         rows[5] = rows[2]
     q = rng.standard_normal((b, dim)).astype(np.float32)
-    what = f"gemv case {case}: n={n} dim={dim} b={b} k={k} {dtype} kp={kp} off={off}"
+    keep = dtype == "f32" or bool(rng.integers(0, 3))      # one bf16 store in three has no fp32 copy (rerank against the bf16 rows)
+    what = f"gemv case {case}: n={n} dim={dim} b={b} k={k} {dtype} kp={kp} off={off} keep_f32={int(keep)}"
     rows_n = oracle.normalize_rows(rows)
-    src = oracle.round_bf16(rows_n) if (dtype == "bf16" and kp == 0) else rows_n
+    src = oracle.round_bf16(rows_n) if (dtype == "bf16" and (kp == 0 or not keep)) else rows_n
     qn = oracle.normalize_rows(q)
-    ix = FlatIndex(dim, dtype, True)
+    ix = FlatIndex(dim, dtype, keep)
     try:
         ix.set_option("mfma_cost_model", int(rng.integers(0, 2)))
         ix.add(rows)
