@@ -143,6 +143,61 @@ void run_regs(const unsigned char* d, long long n_rows, unsigned* sink, const ch
          8 * SLOTS, 8 * SLOTS, ms, bytes / ms / 1e9, bytes / ms / 1e6 / g_blocks);
 }
 
+// The SEG = 128 pattern again, issued as buffer_load_dwordx4 ... lds (SGPR resource + 32-bit per-lane offset + scalar
+// offset) instead of global_load_lds_dwordx4 (64-bit per-lane address): does the address form change the fill rate?
+template <int KEEP, int SLOTS>
+__global__ __launch_bounds__(512) void probe_buf(const unsigned char* __restrict__ src, long long n_rows, int n_stages, int rows_per_block_stage) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  constexpr int RING = KEEP + 1;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int xcd = blockIdx.x & 7;
+  const long long xcd_rows = n_rows / 8;
+  const unsigned char* base = src + (size_t)xcd * xcd_rows * 1536;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(xcd_rows * 1536), 0x00020000);
+  const unsigned lane_off = (unsigned)((lane / 8) * 1536 + (lane % 8) * 16);
+  auto issue = [&](int stage) {
+    const int ks = stage % 12;
+    unsigned char* st = smem + ((stage % RING) * 8 + w) * SLOTS * 1024;
+    const long long win = ((long long)(stage / 12) * rows_per_block_stage) % (xcd_rows - rows_per_block_stage);
+    const unsigned soff = (unsigned)((size_t)win * 1536 + (size_t)ks * 128 + (size_t)w * SLOTS * 8 * 1536);
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(st + i * 1024), 16, lane_off,
+                                           soff + (unsigned)(i * 8 * 1536), 0, 0);
+  };
+#pragma unroll
+  for (int s = 0; s < KEEP; ++s) issue(s);
+  for (int s = 0; s < n_stages; ++s) {
+    issue(s + KEEP);
+    if constexpr (KEEP * SLOTS == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (KEEP * SLOTS == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int KEEP, int SLOTS>
+void run_buf(const unsigned char* d, long long n_rows, const char* what) {
+  const int n_stages = 6000;
+  const int rows_per_block_stage = 8 * SLOTS * 8;
+  const size_t smem = (size_t)(KEEP + 1) * 8 * SLOTS * 1024;
+  CHECK(hipFuncSetAttribute((const void*)probe_buf<KEEP, SLOTS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  for (int rep = 0; rep < 2; ++rep) {
+    CHECK(hipEventRecord(e0));
+    hipLaunchKernelGGL((probe_buf<KEEP, SLOTS>), dim3(g_blocks), dim3(512), smem, 0, d, n_rows, n_stages, rows_per_block_stage);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+  }
+  float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+  const double bytes = (double)g_blocks * n_stages * 8 * SLOTS * 1024;
+  printf("%-34s seg 128 B  kept in flight/CU %3d KiB  stage %2d KiB : %6.2f ms  %6.2f TB/s  %5.1f GB/s per CU\n", what,
+         KEEP * 8 * SLOTS, 8 * SLOTS, ms, bytes / ms / 1e9, bytes / ms / 1e6 / g_blocks);
+}
+
 template <int SEG, int KEEP, int SLOTS, int PRIVATE = 0, int AUX = 0>
 void run(const unsigned char* d, long long n_rows, const char* what) {
   const int n_stages = 6000;
@@ -182,6 +237,9 @@ int main(int argc, char** argv) {
   run<64, 1, 4>(d, n_rows, "32 KiB half-line stages, 1 kept");
   run<64, 2, 4>(d, n_rows, "32 KiB half-line stages, 2 kept");
   run<64, 3, 4>(d, n_rows, "32 KiB half-line stages, 3 kept");
+  run_buf<1, 8>(d, n_rows, "buffer_load lds, 64 KiB, 1 kept");
+  run_buf<2, 4>(d, n_rows, "buffer_load lds, 32 KiB, 2 kept");
+  run<128, 1, 8>(d, n_rows, "64 KiB stages, 1 kept (again)");
   run<128, 1, 8, 0, 1>(d, n_rows, "64 KiB stages, 1 kept, sc0");
   run<128, 1, 8, 0, 2>(d, n_rows, "64 KiB stages, 1 kept, nt");
   run<128, 1, 8, 0, 3>(d, n_rows, "64 KiB stages, 1 kept, sc0 nt");
