@@ -171,6 +171,28 @@ def test_rerank_on_a_store_without_the_fp32_copy_on_the_oracle_twin(oracle_lib, 
     fx.close()
 
 
+def test_collection_without_the_fp32_copy(oracle_lib, oracle_mod, tmp_path):
+    """PersistentClient(dtype="bf16", fp32_copy=False): 2 bytes per element; queries (reranked against the bf16 rows) and
+    include=["embeddings"] work from the stored bf16 rows; reopening WITH the copy rebuilds from the embeddings as added."""
+    rng = np.random.default_rng(8)
+    rows = rng.standard_normal((200, 32)).astype(np.float32)
+    client = PersistentClient(path=str(tmp_path), dtype="bf16", fp32_copy=False, lib=oracle_lib)
+    col = _col(client)
+    col.add(embeddings=rows, ids=[f"i{j}" for j in range(200)])
+    q = rows[[3, 150]] + 0.01
+    res = col.query(query_embeddings=q, n_results=5, include=["embeddings", "distances"])
+    assert [r[0] for r in res["ids"]] == ["i3", "i150"]
+    want = oracle_mod.round_bf16(oracle_mod.normalize_rows(rows[[3]]))[0]
+    assert np.array_equal(np.asarray(res["embeddings"][0][0], np.float32), want)
+    client.close()
+    hdr = open(tmp_path / "c" / "vectors.vdb", "rb").read(16)
+    assert struct.unpack("<ii", hdr[8:16]) == (32, 1)                      # the cache holds bf16 rows
+    col2 = _col(PersistentClient(path=str(tmp_path), dtype="bf16", lib=oracle_lib))      # with the copy: rebuilt, fp32 rows again
+    res2 = col2.query(query_embeddings=q, n_results=5, include=["embeddings", "distances"])
+    assert res2["ids"] == res["ids"]
+    assert np.allclose(res2["embeddings"][0][0], rows[3] / np.linalg.norm(rows[3]), atol=1e-6)
+
+
 def test_batched_best_match_maps_an_empty_answer_to_none(oracle_lib):
     """A product whose embedding is not finite gets no row back from the engine (idx -1 / +inf): it must read
     (None, -1.0) like the reference's loop (generate_best_usda_matches.py:116-143), not the last USDA code."""

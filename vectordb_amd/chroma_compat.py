@@ -39,6 +39,7 @@ from typing import Any, Dict, List, Optional, Sequence
 
 import numpy as np
 
+from ._capi import VdbError
 from .index import FlatIndex
 
 _VALID_INCLUDE = {"embeddings", "metadatas", "documents", "distances", "uris", "data"}
@@ -84,7 +85,7 @@ class Collection:
 
     def __init__(self, name: str, path: Optional[str], embedding_function=None, metadata: Optional[dict] = None,
                  *, dtype: str = "f32", device: int = 0, rerank_kprime: Optional[int] = None, lib=None,
-                 embeddings_as: str = "numpy", auto_persist: bool = True):
+                 embeddings_as: str = "numpy", auto_persist: bool = True, fp32_copy: bool = True):
         metadata = dict(metadata or {})
         space = metadata.get("hnsw:space", "l2")
         if space != "cosine":
@@ -97,7 +98,8 @@ class Collection:
         self._device = device
         self._lib = lib
         self._rerank_kprime = rerank_kprime
-        self._embeddings_as = embeddings_as
+        self._fp32_copy = bool(fp32_copy) or dtype != "bf16"      # bf16 only: 2 instead of 6 bytes per element; the rerank and
+        self._embeddings_as = embeddings_as                        # include=["embeddings"] then work from the stored bf16 rows
         self._auto_persist = auto_persist and path is not None
         self._ids: List[str] = []
         self._id_to_row: Dict[str, int] = {}
@@ -112,7 +114,7 @@ class Collection:
     def _ensure_index(self, dim: int) -> FlatIndex:
         if self._index is None:
             self._dim = dim
-            self._index = FlatIndex(dim, self._dtype, True, self._device, lib=self._lib)
+            self._index = FlatIndex(dim, self._dtype, self._fp32_copy, self._device, lib=self._lib)
         elif dim != self._dim:
             raise ValueError(f"Embedding dimension {dim} does not match collection dimensionality {self._dim}")
         return self._index
@@ -278,7 +280,7 @@ class Collection:
             idx, dist = self._index.search_masked(q, k, mask, self._kprime(k))
             rows = [idx[i][idx[i] >= 0] for i in range(b)]
             return rows, [dist[i][: len(rows[i])] for i in range(b)]
-        sub = FlatIndex(self._dim, self._dtype, True, self._device, lib=self._lib)
+        sub = FlatIndex(self._dim, self._dtype, self._fp32_copy, self._device, lib=self._lib)
         try:
             sub.add(self._stored_rows(allowed))
             k = min(n_results, allowed.size)
@@ -405,9 +407,12 @@ class Collection:
             with open(vdb, "rb") as f:
                 head = f.read(32)
             if len(head) == 32 and int(np.frombuffer(head[16:24], dtype=np.int64)[0]) == count:
-                self._index = FlatIndex.load(d, self._dtype, True, self._device, lib=self._lib)
-                self._vdb_rows = count
-                return
+                try:
+                    self._index = FlatIndex.load(d, self._dtype, self._fp32_copy, self._device, lib=self._lib)
+                    self._vdb_rows = count
+                    return
+                except VdbError:      # e.g. a cache written without the fp32 copy, reopened with one: rebuild below
+                    self._index = None
         # no (or a stale) store file: rebuild the index from the embeddings as they were added
         emb_path, npy_path = os.path.join(d, "embeddings.f32"), os.path.join(d, "embeddings.npy")
         if os.path.exists(emb_path) and os.path.getsize(emb_path) >= count * self._dim * 4:
@@ -447,11 +452,11 @@ class PersistentClient:
 
     def __init__(self, path: str = "./chroma", *, dtype: str = "f32", device: int = 0,
                  rerank_kprime: Optional[int] = None, lib=None, embeddings_as: str = "numpy",
-                 auto_persist: bool = True):
+                 auto_persist: bool = True, fp32_copy: bool = True):
         self._path = str(path)
         os.makedirs(self._path, exist_ok=True)
         self._opts = dict(dtype=dtype, device=device, rerank_kprime=rerank_kprime, lib=lib,
-                          embeddings_as=embeddings_as, auto_persist=auto_persist)
+                          embeddings_as=embeddings_as, auto_persist=auto_persist, fp32_copy=fp32_copy)
         self._open: Dict[str, Collection] = {}
 
     def _exists(self, name: str) -> bool:
@@ -518,7 +523,7 @@ class EphemeralClient(PersistentClient):
         self._path = None
         self._opts = dict(dtype=kw.get("dtype", "f32"), device=kw.get("device", 0),
                           rerank_kprime=kw.get("rerank_kprime"), lib=kw.get("lib"),
-                          embeddings_as=kw.get("embeddings_as", "numpy"), auto_persist=False)
+                          embeddings_as=kw.get("embeddings_as", "numpy"), auto_persist=False, fp32_copy=kw.get("fp32_copy", True))
         self._open = {}
 
     def _exists(self, name: str) -> bool:
