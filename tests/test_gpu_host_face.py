@@ -107,3 +107,29 @@ def test_best_match_harness_hip_equals_oracle(twin_dbs):
     assert agree.mean() >= 0.999
     assert np.allclose(bh["similarity_score"][agree], bo["similarity_score"][agree], rtol=1e-5, atol=2e-6)
     assert analysis.summarize_best_matches(bh)["known"] == analysis.summarize_best_matches(bo)["known"] > 0
+
+
+def test_collection_without_the_fp32_copy_hip_equals_oracle(tmp_path, hip_lib, oracle_lib):
+    """PersistentClient(dtype="bf16", fp32_copy=False) — 2 bytes per element — behind the HIP library and behind the oracle
+    library: the same hits (batched: the streaming MFMA kernel re-scoring against the bf16 rows), the same stored
+    embeddings bit for bit, and a reopen from the bf16-only cache file."""
+    from vectordb_amd.chroma_compat import PersistentClient
+    rng = np.random.default_rng(21)
+    base = rng.standard_normal((67, 768)).astype(np.float32)
+    rows = base[rng.integers(0, 67, 6000)] + 0.4 * rng.standard_normal((6000, 768)).astype(np.float32)
+    q = rows[rng.integers(0, 6000, 40)] + 0.2 * rng.standard_normal((40, 768)).astype(np.float32)
+    out = []
+    for name, lib in (("hip", None), ("ora", oracle_lib)):
+        client = PersistentClient(path=str(tmp_path / name), dtype="bf16", fp32_copy=False, lib=lib)
+        col = client.get_or_create_collection(name="c", metadata={"hnsw:space": "cosine"})
+        col.add(embeddings=rows, ids=[f"i{j}" for j in range(6000)])
+        res = col.query(query_embeddings=q, n_results=10, include=["embeddings", "distances"])
+        client.close()
+        col2 = PersistentClient(path=str(tmp_path / name), dtype="bf16", fp32_copy=False, lib=lib).get_collection("c")
+        res2 = col2.query(query_embeddings=q[:3], n_results=10, include=["distances"])
+        assert res2["ids"] == res["ids"][:3]
+        out.append(res)
+    hip, ora = out
+    assert hip["ids"] == ora["ids"]
+    assert np.allclose(np.asarray(hip["distances"]), np.asarray(ora["distances"]), atol=2e-6)
+    assert np.array_equal(np.asarray(hip["embeddings"], np.float32), np.asarray(ora["embeddings"], np.float32))
