@@ -20,7 +20,7 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 // LDS image of one K=64 stage: 256 rows x 128 B per operand, 16-byte chunk c of row r at r*8 + (c ^ ((r>>1)&7))
 __device__ __forceinline__ unsigned frag_off(int row, int chunk) { return (unsigned)((row * 8 + (chunk ^ ((row >> 1) & 7))) * 16); }
 
-template <int NW, int NWN, int WM, int WN, bool READ_LDS>
+template <int NW, int NWN, int WM, int WN, bool READ_LDS, bool J_OUTER = false>
 __global__ __launch_bounds__(NW * 64) void probe(const unsigned char* __restrict__ rnd, float* __restrict__ out, int iters) {
   extern __shared__ __align__(16) unsigned char smem[];
   unsigned char* sA = smem;
@@ -52,10 +52,17 @@ __global__ __launch_bounds__(NW * 64) void probe(const unsigned char* __restrict
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       if (READ_LDS) load(s ^ 1, s ^ 1, off);
+      if (!J_OUTER) {          // the A fragment stays for NT consecutive MFMAs
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[READ_LDS ? s : 0][i], fb[READ_LDS ? s : 0][j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[READ_LDS ? s : 0][i], fb[READ_LDS ? s : 0][j], acc[i][j], 0, 0, 0);
+      } else {                 // the B fragment stays for MT consecutive MFMAs
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int i = 0; i < MT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[READ_LDS ? s : 0][i], fb[READ_LDS ? s : 0][j], acc[i][j], 0, 0, 0);
+      }
     }
   }
   float t = 0.f;
@@ -66,9 +73,9 @@ __global__ __launch_bounds__(NW * 64) void probe(const unsigned char* __restrict
   out[(size_t)blockIdx.x * (NW * 64) + threadIdx.x] = t;
 }
 
-template <int NW, int NWN, int WM, int WN, bool READ_LDS>
+template <int NW, int NWN, int WM, int WN, bool READ_LDS, bool J_OUTER = false>
 static void run(const char* name, const unsigned char* rnd, float* out, int blocks, int iters) {
-  auto k = probe<NW, NWN, WM, WN, READ_LDS>;
+  auto k = probe<NW, NWN, WM, WN, READ_LDS, J_OUTER>;
   CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 96 << 10));   // 96 KiB: one block per CU
   hipFuncAttributes fa;
   CHECK(hipFuncGetAttributes(&fa, (const void*)k));
@@ -113,6 +120,9 @@ int main(int argc, char** argv) {
   run<4, 2, 128, 128, true>("4 waves 2x2 of 128x128 (1 wave/SIMD,  32 reads / 128 MFMA)", rnd, out, blocks, iters);
   run<8, 4, 128, 64, false>("8 waves 2x4 of 128x64, fragments read once (no LDS traffic)", rnd, out, blocks, iters);
   run<4, 2, 128, 128, false>("4 waves 2x2 of 128x128, fragments read once (no LDS traffic)", rnd, out, blocks, iters);
+  run<8, 4, 128, 64, true, true>("8 waves 2x4 of 128x64, B held over 8 MFMAs (loops swapped)", rnd, out, blocks, iters);
+  run<8, 2, 64, 128, true, true>("8 waves 4x2 of 64x128, B held over 4 MFMAs (loops swapped)", rnd, out, blocks, iters);
   run<8, 4, 128, 64, true>("8 waves 2x4 of 128x64  again (drift check)", rnd, out, blocks, iters);
+  run<8, 2, 64, 128, true>("8 waves 4x2 of 64x128  again (drift check)", rnd, out, blocks, iters);
   return 0;
 }
