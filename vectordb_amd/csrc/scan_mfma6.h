@@ -20,15 +20,32 @@
 //     different bank groups (conflict-free, like the 32-row pattern);
 //   * C layout: lane l holds query (l & 15) of a block and rows 4 (l >> 4) .. +3: one threshold per lane and N-block
 //     (4), the max tree runs over the 32 scores a lane holds for one N-block, then per 4-score group.
+//
+// THE ISSUE ORDER OF A K-STEP IS WRITTEN OUT BY HAND (round 2, late).  Three things hipcc did to the first form of this
+// kernel, found in its assembly, cost 10-13 % of a batch together (profiles/r02_kstep_schedule_ab.json):
+//   * sched_group_barrier pins fix the PATTERN of a position (MFMA, read, MFMA, read, MFMA, load, MFMA) but not WHICH
+//     read fills a slot: the scheduler sank every fragment read to just before the MFMA that needs it, so the three-
+//     position look-ahead existed in the source only.  Now every MFMA slot ends in __builtin_amdgcn_sched_barrier(0) and
+//     the instruction stream is the source order;
+//   * the builtin LDS-DMA load (__builtin_amdgcn_global_load_lds) is a FLAT-encoded instruction with an LDS memory
+//     operand; while one is in flight SIInsertWaitcnts ("pending flat") makes EVERY wait it inserts lgkmcnt(0), so a read
+//     issued three positions ahead was waited for together with the one issued last.  The loads are inline asm here
+//     (scalar base + one per-lane 32-bit offset, M0 set beside them): unknown to the compiler, they leave its counted
+//     lgkmcnt(N) waits intact; vmcnt was counted by hand already;
+//   * values only the epilogue needs (the four query numbers, the threshold patterns, 32 row numbers and their 32
+//     `row < n_rows` compares, each an SGPR pair) were hoisted above the K loop or to the top of every epilogue and
+//     spilled (12 VGPRs, 44 SGPRs through v_writelane, two reloads with s_waitcnt vmcnt(0) inside the loop, which drain
+//     the staging ring).  They are derived where they are used, from values made opaque with empty asm: no spill is left.
 #pragma once
 #include "scan_mfma5.h"
+#pragma clang diagnostic ignored "-Winline-asm"   // m0 on a clobber list (it is reserved; nothing else in these kernels uses it)
 
 namespace vdbk {
 
 typedef float f32x4m_t __attribute__((ext_vector_type(4)));
 
 template <int MODE, int ABL = 0>   // ABL (diagnostic, results invalid): 1 = no staging loads, 2 = no fragment reads / MFMAs,
-                                   // 3 = in-kernel cycle stamps (per wave: load wait, barrier wait, rest) written to `dense`
+                                   // 3 = in-kernel cycle stamps (per wave: load wait, barrier wait, rest, epilogue) written to `dense`
 __global__ __launch_bounds__(kM5Threads) void scan_mfma_wide16_kernel(
     const unsigned char* __restrict__ rows, int n_rows, const unsigned char* __restrict__ qb16, int b, int n_qtiles,
     int n_splits, int tiles_per_split, int n_pass_tiles, int tile_stride, int self0, int xcd_map,
@@ -65,18 +82,17 @@ __global__ __launch_bounds__(kM5Threads) void scan_mfma_wide16_kernel(
   asm volatile("" :: "v"(thr[0]), "v"(thr[1]), "v"(thr[2]), "v"(thr[3]));   // retire the loads before the loop (see scan_mfma3.h)
   // The epilogue's filter runs on the scores' BIT PATTERNS as signed integers (scan_mfma5.h): against a positive
   // threshold "some score >= thr" is "max pattern >= thr's pattern"; a lane whose threshold is not positive gets
-  // INT_MIN, so its filter always fires and the float compare decides.  Derived where it is used (4 registers less).
-  auto thr_pattern = [&](int nt) -> int { return thr[nt] > 0.f ? __float_as_int(thr[nt]) : (int)0x80000000; };
+  // INT_MIN, so its filter always fires and the float compare decides.  Derived where it is used.
 
-  // staging: LDS position L (16-byte units) of an operand image <- row L>>3, global chunk (L&7)^swz;
-  // corpus and query tiles have the same shape, so one set of offsets serves both
-  unsigned g_off[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int L = t * kM5Threads + tid, r = L >> 3, c = (L & 7) ^ ((r >> 1) & 7);
-    g_off[t] = (unsigned)(r * kMfRowBytes + c * 16);
-  }
+  // staging: LDS position L (16-byte units) of an operand image <- row L>>3, global chunk (L&7)^swz; corpus and
+  // query tiles have the same shape, and piece i of a stage (L = i*512 + tid) lies 64 rows behind piece i-1 with
+  // the same chunk, so ONE per-lane offset serves all eight loads of a stage (the piece goes into the scalar base).
+  const unsigned g_off0 = (unsigned)((tid >> 3) * kMfRowBytes + (((tid & 7) ^ ((tid >> 4) & 7)) * 16));
   const int wbase16 = w * 1024;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)smem;
+  auto glds_asm = [&](const unsigned char* sbase, unsigned voff, unsigned lds_dst) {   // 64 lanes x 16 B -> LDS lds_dst + 16 lane
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
+  };
   const unsigned char* qblk = qb16 + (size_t)qbase * kMfRowBytes;
   constexpr size_t kTileBytes = (size_t)kMfBM * kMfRowBytes;
   int g_cur = pass_tile(tile0, tile_stride, skip_n);             // corpus tile being multiplied (scan_mfma.h)
@@ -89,18 +105,16 @@ __global__ __launch_bounds__(kM5Threads) void scan_mfma_wide16_kernel(
     if (ABL == 1) return;
     const bool wrap = s_abs >= kMfSteps;
     const unsigned char* src = (wrap ? tn : ta) + (wrap ? s_abs - kMfSteps : s_abs) * (kMfBK * 2);
-    unsigned char* st = smem + slot * kM5Slot + wbase16;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      if (i >= i0 && i < i1) mf_glds16(src + g_off[i], st + i * (kM5Threads * 16));
+      if (i >= i0 && i < i1) glds_asm(src + i * (64 * kMfRowBytes), g_off0, lds0 + slot * kM5Slot + wbase16 + i * (kM5Threads * 16));
   };
   auto stage_b = [&](int slot, int s_abs, int i0, int i1) {
     if (ABL == 1) return;
     const unsigned char* src = qblk + (s_abs >= kMfSteps ? s_abs - kMfSteps : s_abs) * (kMfBK * 2);
-    unsigned char* st = smem + kM5BaseB + slot * kM5Slot + wbase16;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      if (i >= i0 && i < i1) mf_glds16(src + g_off[i], st + i * (kM5Threads * 16));
+      if (i >= i0 && i < i1) glds_asm(src + i * (64 * kMfRowBytes), g_off0, lds0 + kM5BaseB + slot * kM5Slot + wbase16 + i * (kM5Threads * 16));
   };
 
   // fragment reads: k32 sub-step t uses chunk 4t + c4 of rows l16 + 16*block
@@ -126,24 +140,11 @@ __global__ __launch_bounds__(kM5Threads) void scan_mfma_wide16_kernel(
   };
 
   f32x4m_t acc[8][4];
-  auto mfma4 = [&](int abuf, int bbuf, int mt, bool first) {
+  auto mfma1 = [&](int abuf, int bbuf, int mt, int nt, bool first) {
     if (ABL == 2) return;
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      f32x4m_t c = acc[mt][nt];
-      if (first) c = f32x4m_t{0.f, 0.f, 0.f, 0.f};
-      acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fA[abuf], fB[bbuf][nt], c, 0, 0, 0);
-    }
-  };
-  // one position = 4 MFMAs with nd fragment reads (1 or 2) and nv staging loads (0 or 1) between them
-  auto pin_position = [&](int nd, int nv) {
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-    if (nd >= 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-    if (nd >= 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-    if (nv >= 1) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    f32x4m_t c = acc[mt][nt];
+    if (first) c = f32x4m_t{0.f, 0.f, 0.f, 0.f};
+    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fA[abuf], fB[bbuf][nt], c, 0, 0, 0);
   };
 
   // prologue: stage 0 lands; stage 1 and the corpus half of stage 2 go out; sub-step 0 fragments are read
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(kM5Threads) void scan_mfma_wide16_kernel(
   unsigned long long prof_a = 0, prof_b = 0, prof_c = 0, prof_d = 0, prof_last = 0;
   // one K-step on corpus slot AS and query slot BS (compile-time); ks is a scalar
   auto step = [&](auto as_tag, auto bs_tag, auto first_tag, int ks) {
-    // keep ks opaque: as a literal it is folded into forty-odd per-lane 64-bit source offsets that spill
+    // keep ks opaque: as a literal it is folded into per-step source addresses that are then all kept alive
     asm volatile("" : "+s"(ks));
     constexpr int AS = decltype(as_tag)::value;
     constexpr int BS = decltype(bs_tag)::value;
@@ -190,30 +191,40 @@ __global__ __launch_bounds__(kM5Threads) void scan_mfma_wide16_kernel(
     // Staging loads are spread.  The texture addresser takes one LDS-DMA instruction per ~20 cycles per CU
     // and the issuing wave waits its turn: eight waves issuing eight each right behind the barrier stood
     // ~1000 cycles per step in that queue with no MFMA issued (in-kernel stamps, ABL = 3).  So: the corpus
-    // stage ks+2 here, one load per two MFMAs of sub-step 0 (its slot was released at the previous barrier
-    // and it is needed only at the barrier after next); the query stage ks+2 behind this step's barrier.
+    // stage ks+2 here, one load per position of sub-step 0's first half (its slot was released at the previous
+    // barrier and it is needed only at the barrier after next); the query stage ks+2 behind this step's barrier.
     // Other placements (2+2 over two sub-steps, sub-step 1, 3/2/1/2) measured the same or worse.
     constexpr int A2 = (AS + 2) % kM5SlotsA;   // the corpus slot released at the previous step's barrier
     constexpr int AN = (AS + 1) % kM5SlotsA;   // next stage's slots (readable behind this step's barrier)
-    // positions 0..11: this stage only.  Position p reads the A fragment of position p + 3; positions 4..7 read the
-    // B fragments of k32 #1; positions 0..3 issue the corpus stage ks+2 (one load each).
+    // positions 0..11: this stage only.  Position p = MFMA, A fragment of position p + 3, MFMA, (positions 4..7: a B
+    // fragment of k32 #1), MFMA, (positions 0..3: one load of the corpus stage ks+2), MFMA - in THIS order: every
+    // slot is fenced (see the head of this file).
 #pragma unroll
     for (int p = 0; p < 12; ++p) {
       const int pa = p + 3;
+      const bool zero = first && p < 8;
+      mfma1(p & 3, p >> 3, p & 7, 0, zero);
       read_a1(pa & 3, AS, pa >> 3, pa & 7);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma1(p & 3, p >> 3, p & 7, 1, zero);
       if (p >= 4 && p < 8) read_b1(1, BS, 1, p - 4);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma1(p & 3, p >> 3, p & 7, 2, zero);
       if (p < 4) stage_a(A2, ks + 2, p, p + 1);
-      mfma4(p & 3, p >> 3, p & 7, first && p < 8);
-      pin_position((p >= 4 && p < 8) ? 2 : 1, p < 4 ? 1 : 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma1(p & 3, p >> 3, p & 7, 3, zero);
+      __builtin_amdgcn_sched_barrier(0);
     }
     unsigned long long t1 = 0, t2 = 0;
     if (ABL == 3) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); t1 = __builtin_readcyclecounter(); }
-    // all but my newest four loads (corpus stage ks+2, issued in this step) have landed, every read of
-    // this stage has returned.
-    // (The first step of a tile follows an epilogue whose stores and atomics share the counter and may
-    // complete out of order with the loads: there the count proves nothing, so it drains to zero.)
-    if (first) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    // All but my newest four loads (corpus stage ks+2, issued in this step) have landed.  No wait for fragment reads:
+    // every read of the slot about to be refilled (the query slot) was issued before position 8 and has returned -
+    // the MFMAs of position 11 waited for a read issued after them.
+    // (The first step of a tile follows an epilogue whose stores and atomics share the counter and may complete out of
+    // order with the loads: it drains to zero.  Loads return in order AMONG LOADS, so "at most 4 outstanding" with four
+    // younger loads issued would prove the older ones landed anyway - but dropping the drain gained nothing, measured.)
+    if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     if (ABL == 3) t2 = __builtin_readcyclecounter();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -229,11 +240,17 @@ __global__ __launch_bounds__(kM5Threads) void scan_mfma_wide16_kernel(
 #pragma unroll
     for (int p = 12; p < 16; ++p) {
       const int pa = p + 3;
+      mfma1(p & 3, 1, p & 7, 0, false);
       if (pa < 16) read_a1(pa & 3, AS, 1, pa & 7); else read_a1(pa & 3, AN, 0, pa - 16);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma1(p & 3, 1, p & 7, 1, false);
       read_b1(0, BS ^ 1, 0, p - 12);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma1(p & 3, 1, p & 7, 2, false);
       stage_b(BS, ks + 2, p - 12, p - 11);
-      mfma4(p & 3, 1, p & 7, false);
-      pin_position(2, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma1(p & 3, 1, p & 7, 3, false);
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
   using I0 = std::integral_constant<int, 0>;
@@ -253,6 +270,8 @@ __global__ __launch_bounds__(kM5Threads) void scan_mfma_wide16_kernel(
     step(I0{}, I1{}, I0{}, 9);
     step(I1{}, I0{}, I0{}, 10);
     step(I2{}, I1{}, I0{}, 11);
+    unsigned long long te0 = 0;
+    if (ABL == 3) te0 = __builtin_readcyclecounter();
     const long long tile_row0 = (long long)g_cur * kMfBM;
     ta = tn;
     g_cur = g_nxt;
@@ -263,7 +282,9 @@ __global__ __launch_bounds__(kM5Threads) void scan_mfma_wide16_kernel(
     const bool needs_mask = (tile_row0 + kMfBM > n_rows) || (qbase + kM5BN > b) || (self0 >= 0);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
-      const int qg = qbase + wn * 64 + nt * 16 + l16;
+      int l16e = l16;
+      asm volatile("" : "+v"(l16e));   // derived per tile: hoisted, qg and what follows from it live across the K loop
+      const int qg = qbase + wn * 64 + nt * 16 + l16e;
       if (MODE == 0) {
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt)
@@ -281,15 +302,22 @@ __global__ __launch_bounds__(kM5Threads) void scan_mfma_wide16_kernel(
           m8[mt] = max(max(__float_as_int(acc[mt][nt][0]), __float_as_int(acc[mt][nt][1])),
                        max(__float_as_int(acc[mt][nt][2]), __float_as_int(acc[mt][nt][3])));
         const int m = max(max(max(m8[0], m8[1]), max(m8[2], m8[3])), max(max(m8[4], m8[5]), max(m8[6], m8[7])));
-        const int tb = thr_pattern(nt);
+        float thr_e = thr[nt];
+        asm volatile("" : "+v"(thr_e));   // likewise: the four patterns are not worth four registers across the K loop
+        const int tb = thr_e > 0.f ? __float_as_int(thr_e) : (int)0x80000000;
         if (__ballot(m >= tb) != 0ull) {
 #pragma unroll
           for (int mt = 0; mt < 8; ++mt) {
             if (__ballot(m8[mt] >= tb) == 0ull) continue;
+            // The row numbers are derived HERE, behind the branch and from an opaque value: computable from loop
+            // invariants, hipcc otherwise hoists all 32 of them and their 32 `row < n_rows` compares (each an SGPR
+            // pair spilled through v_writelane) to the top of every epilogue, hit or no hit - 12 % of the kernel.
+            int rbase = wm * 128 + mt * 16 + 4 * c4;
+            asm volatile("" : "+v"(rbase));
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const float v = acc[mt][nt][e];
-              const int row = (int)tile_row0 + wm * 128 + mt * 16 + 4 * c4 + e;
+              const int row = (int)tile_row0 + rbase + e;
               bool pass = v >= thr[nt];
               if (needs_mask) pass = pass && (row < n_rows) && (qg < b) && !(self0 >= 0 && row == self0 + qg);
               if (__ballot(pass) == 0ull) continue;
@@ -305,6 +333,7 @@ __global__ __launch_bounds__(kM5Threads) void scan_mfma_wide16_kernel(
         }
       }
     }
+    if (ABL == 3) prof_d += __builtin_readcyclecounter() - te0;   // the epilogue's share of "rest"
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing (unused) staging loads
   if (MODE == 1) flush_pending();
