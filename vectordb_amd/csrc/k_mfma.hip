@@ -33,7 +33,7 @@ bool mfma_kk_supported(int kk) { return mfma_path_supported(kk); }
 //   b <= 64                         -> 6: the streaming kernel (scan_stream.h): corpus straight from HBM into MFMA
 //                                         fragments, no LDS staging of the corpus — HBM-bound like the GEMV scan;
 //   a 256-wide query tile pads the batch no more than 1.5x further than a 128-wide one -> 5 (scan_mfma5.h; it runs
-//                                         ~1.6x the rate of the 128-wide kernel: 13.4 vs 21.8 ms per 1024 queries x 10M rows);
+//                                         ~1.9x the rate of the 128-wide kernel: 11.2 vs 21.8 ms per 1024 queries x 10M rows; only b <= 128 fails the test);
 //   otherwise                       -> 4 (scan_mfma4.h).
 MfPlan mfma_plan(int b, int n_rows, int n_cu, int variant_opt) {
   (void)n_rows;
