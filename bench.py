@@ -166,8 +166,7 @@ def traffic_pass(args):
                         per.setdefault(r["Kernel_Name"], []).append(2.0 * 1024.0 * float(r["Counter_Value"]))
         out = {}
         for name, vals in per.items():
-            fam = next((f for f in ("scan_topk_kernel", "scan_mfma_wide16_kernel<1", "scan_mfma_ws_kernel<1",
-                                    "scan_stream_lds_kernel<1", "probe_read_kernel") if f in name), None)
+            fam = next((f for f in ("scan_topk_kernel", "scan_mfma_wide16_kernel<1", "scan_stream_lds_kernel<1", "probe_read_kernel") if f in name), None)
             if fam is None:
                 continue
             big = [v for v in vals if v >= 0.5 * max(vals)]      # the batched kernels launch twice per batch: the last pass is the large one
@@ -267,9 +266,12 @@ def measure(sh, args, b, steps, warmup, qspec, device, world, n_local):
     esz = 2 if args.dtype == "bf16" else 4
     path = sh.local.get_stat("last_path")            # 0 = GEMV scan, 4/5 = MFMA pass kernels, 6 = streaming MFMA kernel
     scan_ms = tstats["scan_ms_sum"] / max(tstats["n"], 1)
-    kernel = {0: "scan_topk_kernel", 4: "scan_mfma_ws_kernel<1> + sample passes", 5: "scan_mfma_wide16_kernel<1> + sample passes",
+    kernel = {0: "scan_topk_kernel", 4: "scan_mfma_wide16_kernel<1, 0, 2> (128-wide query tile) + sample passes", 5: "scan_mfma_wide16_kernel<1> + sample passes",
               6: "scan_stream_lds_kernel<1> + sample passes"}.get(path, f"path {path}")
-    if path in (4, 5):
+    # one query tile covers the batch (the corpus comes from HBM once) and b flop per byte is under the ridge of
+    # 2500 TFLOP/s / 8 TB/s = 312: such a batch is HBM-bound like a single query, whichever kernel serves it
+    one_tile_hbm_bound = path in (4, 5) and b <= (256 if path == 5 else 128) and 2.0 * b / esz < MFMA_BF16_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBPS
+    if path in (4, 5) and not one_tile_hbm_bound:
         alg = 2.0 * b * n_local * dim
         roof = {"bound": "mfma", "achieved": alg / (scan_ms * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s"}
         # operand bytes staged through LDS per batch: the path that actually binds the kernel
@@ -278,9 +280,10 @@ def measure(sh, args, b, steps, warmup, qspec, device, world, n_local):
         roof["lds_staged_bytes"] = float(n_local) * dim * esz * b_pad * (1.0 / bn + 1.0 / 256)
         roof["lds_staging_TBps"] = roof["lds_staged_bytes"] / (scan_ms * 1e-3) / 1e12
     else:
-        alg = float(n_local) * dim * esz * sh.local.get_stat("last_corpus_passes")   # bytes per corpus pass x passes of the batch
+        passes = 1 if one_tile_hbm_bound else sh.local.get_stat("last_corpus_passes")
+        alg = float(n_local) * dim * esz * passes   # bytes per corpus pass x passes of the batch
         roof = {"bound": "hbm", "achieved": alg / (scan_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "corpus_passes_per_batch": sh.local.get_stat("last_corpus_passes")}
+                "corpus_passes_per_batch": passes}
     roof["frac"] = roof["achieved"] / roof["peak"]
     # the same ceilings as measured on this device (streaming read of the store in the scan's own launch shape;
     # bare bf16 MFMA loop)

@@ -33,8 +33,9 @@ bool mfma_kk_supported(int kk) { return mfma_path_supported(kk); }
 //   b <= 64                         -> 6: the streaming kernel (scan_stream.h): corpus straight from HBM into MFMA
 //                                         fragments, no LDS staging of the corpus — HBM-bound like the GEMV scan;
 //   a 256-wide query tile pads the batch no more than 1.5x further than a 128-wide one -> 5 (scan_mfma5.h; it runs
-//                                         ~1.9x the rate of the 128-wide kernel: 11.2 vs 21.8 ms per 1024 queries x 10M rows; only b <= 128 fails the test);
-//   otherwise                       -> 4 (scan_mfma4.h).
+//                                         ~1.9x the rate of the 128-wide tiles per query; only b <= 128 fails the test);
+//   otherwise                       -> 4: the same kernel on a 128-wide query tile (scan_mfma6.h, NB = 2; it replaced the
+//                                         warp-specialised 256x128 kernel of round 1: 2.74 / 2.78 vs 2.90 / 3.15 ms at 65 / 128 queries).
 MfPlan mfma_plan(int b, int n_rows, int n_cu, int variant_opt) {
   (void)n_rows;
   MfPlan p;
@@ -52,7 +53,6 @@ MfPlan mfma_plan(int b, int n_rows, int n_cu, int variant_opt) {
 
 hipError_t mfma_prepare_device() {
   MF_TRY(hipFuncSetAttribute((const void*)scan_mfma_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mf_smem_bytes()));
-  MF_TRY(ws_prepare_device());
   MF_TRY(wide16_prepare_device());
   MF_TRY(stream_prepare());
   return hipSuccess;
@@ -87,7 +87,8 @@ hipError_t mfma_search_launch(const MfSearchArgs& a, int* skipped_tiles) {
     p.ovf = ovf; p.ablate = a.ablate; p.st = st;
     if (variant == 6) return stream_pass(p, a.n_cu, a.stream_nt);
     if (variant == 5) return wide16_launch_pass(p);
-    return ws_launch_pass(p);
+    p.narrow = 1;   // variant 4: the 128-wide query tile of the same kernel
+    return wide16_launch_pass(p);
   };
 
   // pass 0: dense scores of a strided 16-tile sample -> t0 = a lower bound of the k'-th best per query

@@ -1,6 +1,6 @@
 // launch.h — host-side seams between the translation units of libvdb_hip.so.
 // The kernels are heavy template families (72 GEMV-scan instantiations, the MFMA pass kernels);
-// each family compiles in its own TU (k_gemv.hip; k_mfma.hip and, behind mfma_pass.h, k_mfma_ws/_wide16.hip, k_stream.hip) so that the library
+// each family compiles in its own TU (k_gemv.hip; k_mfma.hip and, behind mfma_pass.h, k_mfma_wide16.hip, k_stream.hip) so that the library
 // builds in parallel and a change to one kernel rebuilds one file.  vdb_api.hip (the C ABI and all
 // orchestration) sees only these plain functions.  No device symbol crosses a TU.
 #pragma once

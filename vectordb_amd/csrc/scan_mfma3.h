@@ -17,7 +17,7 @@
 // Extra work: the samples add ~1-2 % to the contraction.
 //
 // This header holds the protocol's selection kernels; the pass kernels themselves are
-// scan_mfma4.h (256 x 128 tile, warp-specialised), scan_mfma5.h (256 x 256 tile) and
+// scan_mfma5.h / scan_mfma6.h (256 x 256 and 256 x 128 tiles) and
 // scan_stream.h (<= 64 queries, corpus straight from HBM into MFMA fragments).  The first
 // pass kernel of this protocol (a barrier ring on a 256 x 128 tile) was retired in round 2:
 // no shape was left where it won.

@@ -4,7 +4,7 @@
 // shape) and was retired in round 2 — what is said below about sub-steps of k16 describes it, scan_mfma6.h restates the
 // K-step for 16x16x32.
 //
-// Why: the 256x128 kernels (scan_mfma3.h / scan_mfma4.h) stage (1/128 + 1/256) bytes per
+// Why: 256x128 tiles (the round-1 kernels; today scan_mfma6.h with NB = 2, for batches of at most 128 queries) stage (1/128 + 1/256) bytes per
 // multiply-add column pair through LDS — 184 GB for 10M x 768 against 1024 queries — and the
 // L2 -> LDS path delivers at most ~56 GB/s per CU (14.3 TB/s chip-wide; benchmarks/
 // lds_dma_probe.hip): 12.9 ms of operand delivery, longer than the MFMA work itself.  A

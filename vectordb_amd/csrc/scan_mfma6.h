@@ -44,7 +44,10 @@ namespace vdbk {
 
 typedef float f32x4m_t __attribute__((ext_vector_type(4)));
 
-template <int MODE, int ABL = 0>   // ABL (diagnostic, results invalid): 1 = no staging loads, 2 = no fragment reads / MFMAs,
+// NB = query blocks of 16 per wave: 4 = the 256-wide query tile described above; 2 = the same kernel on a 128-wide query
+// tile (a wave owns 128 rows x 32 queries, a position is 2 MFMAs, a query stage is 16 KiB = two pieces per wave; same LDS
+// layout with half of each query slot unused) for batches of 65...128 queries, where a 256-wide tile would be half padding.
+template <int MODE, int ABL = 0, int NB = 4>   // ABL (diagnostic, results invalid): 1 = no staging loads, 2 = no fragment reads / MFMAs,
                                    // 3 = in-kernel cycle stamps (per wave: load wait, barrier wait, rest, epilogue) written to `dense`
 __global__ __launch_bounds__(kM5Threads) void scan_mfma_wide16_kernel(
     const unsigned char* __restrict__ rows, int n_rows, const unsigned char* __restrict__ qb16, int b, int n_qtiles,
@@ -67,19 +70,28 @@ __global__ __launch_bounds__(kM5Threads) void scan_mfma_wide16_kernel(
     qt = blockIdx.x % n_qtiles;
     sp = blockIdx.x / n_qtiles;
   }
-  const int qbase = qt * kM5BN;
+  constexpr int kBN = 64 * NB;   // queries per block
+  // Query slots: two of 32 KiB for the 256-wide tile (all of LDS with the three corpus slots).  The 128-wide tile's
+  // stages are 16 KiB, so THREE fit (144 KiB in all) and its query stages run one further ahead: its K-steps are half as
+  // long (32 MFMAs per wave), and a query stage issued behind one barrier and needed at the next had ~0.6 us to land.
+  constexpr int kSlotsB = NB == 2 ? 3 : 2;
+  constexpr int kSlotB = NB == 2 ? kM5Slot / 2 : kM5Slot;
+  const int qbase = qt * kBN;
   const int tile0 = sp * tiles_per_split;
   const int tile1 = min(tile0 + tiles_per_split, n_pass_tiles);
   const int my_tiles = tile1 > tile0 ? tile1 - tile0 : 0;
   if (my_tiles == 0) return;
 
-  float thr[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-  if (MODE == 1 && thr_in) {
-    const int q0 = qbase + wn * 64 + l16;
+  float thr[NB];
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) thr[nt] = thr_in[min(q0 + 16 * nt, b - 1)];
+  for (int nt = 0; nt < NB; ++nt) thr[nt] = -INFINITY;
+  if (MODE == 1 && thr_in) {
+    const int q0 = qbase + wn * (16 * NB) + l16;
+#pragma unroll
+    for (int nt = 0; nt < NB; ++nt) thr[nt] = thr_in[min(q0 + 16 * nt, b - 1)];
   }
-  asm volatile("" :: "v"(thr[0]), "v"(thr[1]), "v"(thr[2]), "v"(thr[3]));   // retire the loads before the loop (see scan_mfma3.h)
+#pragma unroll
+  for (int nt = 0; nt < NB; ++nt) asm volatile("" :: "v"(thr[nt]));   // retire the loads before the loop (see scan_mfma3.h)
   // The epilogue's filter runs on the scores' BIT PATTERNS as signed integers (scan_mfma5.h): against a positive
   // threshold "some score >= thr" is "max pattern >= thr's pattern"; a lane whose threshold is not positive gets
   // INT_MIN, so its filter always fires and the float compare decides.  Derived where it is used.
@@ -113,14 +125,14 @@ __global__ __launch_bounds__(kM5Threads) void scan_mfma_wide16_kernel(
     if (ABL == 1) return;
     const unsigned char* src = qblk + (s_abs >= kMfSteps ? s_abs - kMfSteps : s_abs) * (kMfBK * 2);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      if (i >= i0 && i < i1) glds_asm(src + i * (64 * kMfRowBytes), g_off0, lds0 + kM5BaseB + slot * kM5Slot + wbase16 + i * (kM5Threads * 16));
+    for (int i = 0; i < NB; ++i)   // a query stage is NB pieces per wave
+      if (i >= i0 && i < i1) glds_asm(src + i * (64 * kMfRowBytes), g_off0, lds0 + kM5BaseB + slot * kSlotB + wbase16 + i * (kM5Threads * 16));
   };
 
   // fragment reads: k32 sub-step t uses chunk 4t + c4 of rows l16 + 16*block
   const int swz = (l16 >> 1) & 7;
   const int a_row_off = (wm * 128 + l16) * 128;
-  const int b_row_off = kM5BaseB + (wn * 64 + l16) * 128;
+  const int b_row_off = kM5BaseB + (wn * (16 * NB) + l16) * 128;
   int ck[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t) ck[t] = ((4 * t + c4) ^ swz) << 4;
@@ -129,17 +141,17 @@ __global__ __launch_bounds__(kM5Threads) void scan_mfma_wide16_kernel(
   // blocks).  A fragments roll through a ring of four (position p uses fA[p & 3]; its read is issued three positions,
   // 192 cycles, ahead); the four B fragments of a k32 are double-buffered (fB[t & 1]), read one per position during
   // the second half of the previous k32.  48 fragment registers, as in scan_mfma5.h.
-  bf16x8_t fA[4], fB[2][4];
+  bf16x8_t fA[4], fB[2][NB];
   auto read_a1 = [&](int abuf, int aslot, int t, int mt) {
     if (ABL == 2) return;
     fA[abuf] = *reinterpret_cast<const bf16x8_t*>(smem + aslot * kM5Slot + a_row_off + ck[t] + mt * 2048);
   };
   auto read_b1 = [&](int bbuf, int bslot, int t, int nt) {
     if (ABL == 2) return;
-    fB[bbuf][nt] = *reinterpret_cast<const bf16x8_t*>(smem + bslot * kM5Slot + b_row_off + ck[t] + nt * 2048);
+    fB[bbuf][nt] = *reinterpret_cast<const bf16x8_t*>(smem + bslot * kSlotB + b_row_off + ck[t] + nt * 2048);
   };
 
-  f32x4m_t acc[8][4];
+  f32x4m_t acc[8][NB];
   auto mfma1 = [&](int abuf, int bbuf, int mt, int nt, bool first) {
     if (ABL == 2) return;
     f32x4m_t c = acc[mt][nt];
@@ -148,18 +160,19 @@ __global__ __launch_bounds__(kM5Threads) void scan_mfma_wide16_kernel(
   };
 
   // prologue: stage 0 lands; stage 1 and the corpus half of stage 2 go out; sub-step 0 fragments are read
-  stage_b(0, 0, 0, 4);
+  stage_b(0, 0, 0, NB);
   stage_a(0, 0, 0, 4);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  stage_b(1, 1, 0, 4);
+  stage_b(1, 1, 0, NB);
   stage_a(1, 1, 0, 4);
+  if (kSlotsB == 3) stage_b(2, 2, 0, NB);
   read_a1(0, 0, 0, 0);
   read_a1(1, 0, 0, 1);
   read_a1(2, 0, 0, 2);
 #pragma unroll
-  for (int nt = 0; nt < 4; ++nt) read_b1(0, 0, 0, nt);
+  for (int nt = 0; nt < NB; ++nt) read_b1(0, 0, 0, nt);
 
   // A hit waits in its lane's registers (kPend places per lane) until some lane needs one more; then every
   // waiting hit reserves its slot in its query's candidate buffer at once.  The returning atomic (~1 us, and
@@ -186,7 +199,7 @@ __global__ __launch_bounds__(kM5Threads) void scan_mfma_wide16_kernel(
     // keep ks opaque: as a literal it is folded into per-step source addresses that are then all kept alive
     asm volatile("" : "+s"(ks));
     constexpr int AS = decltype(as_tag)::value;
-    constexpr int BS = decltype(bs_tag)::value;
+    constexpr int BS = kSlotsB == 3 ? decltype(as_tag)::value : decltype(bs_tag)::value;   // stage ks sits in query slot ks % kSlotsB
     constexpr bool first = decltype(first_tag)::value != 0;
     // Staging loads are spread.  The texture addresser takes one LDS-DMA instruction per ~20 cycles per CU
     // and the issuing wave waits its turn: eight waves issuing eight each right behind the barrier stood
@@ -203,17 +216,14 @@ __global__ __launch_bounds__(kM5Threads) void scan_mfma_wide16_kernel(
     for (int p = 0; p < 12; ++p) {
       const int pa = p + 3;
       const bool zero = first && p < 8;
-      mfma1(p & 3, p >> 3, p & 7, 0, zero);
-      read_a1(pa & 3, AS, pa >> 3, pa & 7);
-      __builtin_amdgcn_sched_barrier(0);
-      mfma1(p & 3, p >> 3, p & 7, 1, zero);
-      if (p >= 4 && p < 8) read_b1(1, BS, 1, p - 4);
-      __builtin_amdgcn_sched_barrier(0);
-      mfma1(p & 3, p >> 3, p & 7, 2, zero);
-      if (p < 4) stage_a(A2, ks + 2, p, p + 1);
-      __builtin_amdgcn_sched_barrier(0);
-      mfma1(p & 3, p >> 3, p & 7, 3, zero);
-      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int nt = 0; nt < NB; ++nt) {
+        mfma1(p & 3, p >> 3, p & 7, nt, zero);
+        if (nt == 0) read_a1(pa & 3, AS, pa >> 3, pa & 7);
+        if (nt == 1 && p >= 4 && p < 4 + NB) read_b1(1, BS, 1, p - 4);
+        if (nt == (NB == 4 ? 2 : 1) && p < 4) stage_a(A2, ks + 2, p, p + 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     unsigned long long t1 = 0, t2 = 0;
     if (ABL == 3) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); t1 = __builtin_readcyclecounter(); }
@@ -223,7 +233,9 @@ __global__ __launch_bounds__(kM5Threads) void scan_mfma_wide16_kernel(
     // (The first step of a tile follows an epilogue whose stores and atomics share the counter and may complete out of
     // order with the loads: it drains to zero.  Loads return in order AMONG LOADS, so "at most 4 outstanding" with four
     // younger loads issued would prove the older ones landed anyway - but dropping the drain gained nothing, measured.)
+    // (With three query slots the query stage issued behind the previous barrier may still be in flight as well.)
     if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (kSlotsB == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     if (ABL == 3) t2 = __builtin_readcyclecounter();
     __builtin_amdgcn_s_barrier();
@@ -240,17 +252,15 @@ __global__ __launch_bounds__(kM5Threads) void scan_mfma_wide16_kernel(
 #pragma unroll
     for (int p = 12; p < 16; ++p) {
       const int pa = p + 3;
-      mfma1(p & 3, 1, p & 7, 0, false);
-      if (pa < 16) read_a1(pa & 3, AS, 1, pa & 7); else read_a1(pa & 3, AN, 0, pa - 16);
-      __builtin_amdgcn_sched_barrier(0);
-      mfma1(p & 3, 1, p & 7, 1, false);
-      read_b1(0, BS ^ 1, 0, p - 12);
-      __builtin_amdgcn_sched_barrier(0);
-      mfma1(p & 3, 1, p & 7, 2, false);
-      stage_b(BS, ks + 2, p - 12, p - 11);
-      __builtin_amdgcn_sched_barrier(0);
-      mfma1(p & 3, 1, p & 7, 3, false);
-      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int nt = 0; nt < NB; ++nt) {
+        mfma1(p & 3, 1, p & 7, nt, false);
+        if (nt == 0) { if (pa < 16) read_a1(pa & 3, AS, 1, pa & 7); else read_a1(pa & 3, AN, 0, pa - 16); }
+        if (nt == 1 && p - 12 < NB) read_b1(0, (BS + 1) % kSlotsB, 0, p - 12);
+        if (NB == 4 && nt == 2) stage_b(BS, ks + kSlotsB, p - 12, p - 11);
+        if (NB == 2 && nt == 1 && p >= 14) stage_b(BS, ks + kSlotsB, p - 14, p - 13);   // the two positions without a B read
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   };
   using I0 = std::integral_constant<int, 0>;
@@ -279,12 +289,12 @@ __global__ __launch_bounds__(kM5Threads) void scan_mfma_wide16_kernel(
     if (ablate & 4) continue;   // ablate bit 2: no epilogue (diagnostic, results invalid)
 
     // ---------------- epilogue of pass-local tile (tile0 + tile) ----------------
-    const bool needs_mask = (tile_row0 + kMfBM > n_rows) || (qbase + kM5BN > b) || (self0 >= 0);
+    const bool needs_mask = (tile_row0 + kMfBM > n_rows) || (qbase + kBN > b) || (self0 >= 0);
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
+    for (int nt = 0; nt < NB; ++nt) {
       int l16e = l16;
       asm volatile("" : "+v"(l16e));   // derived per tile: hoisted, qg and what follows from it live across the K loop
-      const int qg = qbase + wn * 64 + nt * 16 + l16e;
+      const int qg = qbase + wn * (16 * NB) + nt * 16 + l16e;
       if (MODE == 0) {
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt)

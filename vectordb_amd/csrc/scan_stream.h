@@ -3,7 +3,7 @@
 //
 // Why: a batch of up to 64 queries is as HBM-bound as one query (intensity <= 64 flop/B against a ridge of 312), but the
 // GEMV scan (scan_gemv.h) pays FMAs and a wave reduction per query (4 queries per pass cost 1.64x one), and the tiled MFMA
-// kernels (scan_mfma4.h/6.h) stage the corpus through block-shared LDS tiles for a reuse one query tile does not have.
+// kernels (scan_mfma6.h) stage the corpus through block-shared LDS tiles for a reuse one query tile does not have.
 //   * a wave owns 16 corpus rows at a time and multiplies them with v_mfma_f32_16x16x32_bf16 (A = 16 rows x 32 K) against
 //     NQ blocks of 16 queries;
 //   * the (<= 64) queries live in LDS for the whole kernel as the B operand, rows padded to 1552 bytes so that the 16

@@ -96,7 +96,7 @@ struct vdb {
                                  // kernel: the sample pass costs no extra bytes — the last pass leaves its tiles out — and every hit
                                  // of the last pass stalls a wave's load ring: 2.57 -> 2.46 ms at 3 queries, 2.52 -> 2.45 at 64, 10M rows;
                                  // 650 is as fast but fills the sample pass's candidate buffers to half their capacity)
-  int mfma_variant = 6;          // 4 = warp-specialised 256x128 tile (scan_mfma4.h); 5 = + the 256x256 tile (scan_mfma5.h)
+  int mfma_variant = 6;          // 4 = 128-wide query tiles only; 5 = + the 256-wide tile (both scan_mfma6.h)
                                  // where it pads the batch <= 1.5x further; 6 = + the streaming kernel (scan_stream.h) for <= 64 queries
   int mfma_last_b = 0;           // batch size of the last MFMA search (locates its overflow flag)
   int mfma_last_skipped = 0;     // tiles the last MFMA search's final pass left out (the sample pass's)
