@@ -301,7 +301,7 @@ def test_mfma_multi_tile_per_block_and_selfjoin(hip_lib, oracle_mod):
 
 @pytest.mark.parametrize("variant", [4])
 def test_mfma_kernel_variants_agree(hip_lib, oracle_mod, corpus20k, variant):
-    """The tiled pass-kernel formulations (warp-specialised 256x128, wide 256x256) are
+    """The tiled pass-kernel formulations (256x128 and 256x256 tiles of the wide kernel) are
     interchangeable: same ids and distances on the same batch."""
     n, dim, spec, rows, _ = corpus20k
     qspec = SynthSpec(seed=4242, kind=2, noise=0.5, base_kind=1, base_seed=1234, base_n=n, base_n_clusters=141, base_noise=0.3)
@@ -621,7 +621,7 @@ def test_gemv_batches_beyond_one_query_chunk(hip_lib, oracle_mod, corpus20k):
     ix.close()
 
 
-@pytest.mark.parametrize("b", [100, 300])                       # 128-wide (warp-specialised) and 256-wide kernels
+@pytest.mark.parametrize("b", [100, 300])                       # 128-wide and 256-wide query tiles
 def test_mfma_last_pass_skips_the_sampled_tiles(hip_lib, oracle_mod, corpus20k, b):
     """Two append passes (forced at 20k rows by a small candidate buffer): the last pass leaves out the tiles
     the sample pass multiplied and the final selection is seeded with the sample's list.  Exact against the

@@ -124,7 +124,7 @@ def test_stream_kernel_overflow_fallback_and_bad_thresholds(hip_lib, oracle_mod,
 
 
 def test_wide_kernel_against_the_other_families(hip_lib, oracle_mod):
-    """The wide tile (256 x 256 on v_mfma_f32_16x16x32_bf16) against the 128-wide kernel: same candidates, so the same ids
+    """The wide tile (256 x 256 on v_mfma_f32_16x16x32_bf16) against the same kernel on 128-wide query tiles: same candidates, so the same ids
     and distances bit for bit — several corpus tiles per block, ragged last corpus tile, ragged query tile, self-join
     exclusion, and the oracle's answer."""
     n, dim, b = 140_003, 768, 450
