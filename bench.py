@@ -328,6 +328,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         self_launch(args)                      # does not return
+    # stdout carries the ONE JSON line and nothing else: whatever libraries write to file descriptor 1 (RCCL prints a
+    # version banner there when a communicator is created) goes to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     traffic, traffic_note = None, "not collected (--no-traffic-pass, or more than one rank)"
     profiled = any(k.startswith(("ROCP", "ROCPROF")) for k in os.environ) or "HSA_TOOLS_LIB" in os.environ or \
         "rocprof" in os.environ.get("LD_PRELOAD", "")
@@ -419,7 +424,8 @@ def main():
             blk["roofline"]["traffic_source"] = traffic_note if got or traffic is None else "the counter pass saw no launch of " + fam
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dim, k, n, args.seed)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     sh.close()
     if dist.is_initialized():
         dist.destroy_process_group()
