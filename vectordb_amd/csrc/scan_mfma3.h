@@ -92,20 +92,41 @@ __global__ __launch_bounds__(1024) void select_kth_kernel(const float* __restric
 // Also clears the query's append counter for the first append pass.
 __global__ __launch_bounds__(64) void dense_lower_bound_kernel(const float* __restrict__ scores, int ld, int n, int kk,
                                                                float* __restrict__ thr_out, int* __restrict__ cand_cnt) {
+  // kk-th largest of 256 strided group maxima (4 per lane; groups of 16 at n = 4096): about 1.06 % of a query's scores
+  // lie above it, against 0.98 % for the exact kk-th best of the sample (kk = 40) - and 1.5 % for the 64 group maxima
+  // this kernel used first: a third fewer hits in the sample pass, which is bound by its appends.
+  constexpr int G = 4;
   const int q = blockIdx.x;
   const int lane = threadIdx.x;
   const float* cs = scores + (size_t)q * ld;
-  float v = -INFINITY;
-  for (int i = lane; i < n; i += 64) v = fmaxf(v, cs[i]);
-  // bitonic sort of the 64 maxima, descending by lane
+  float v[G];
 #pragma unroll
-  for (int k = 2; k <= 64; k <<= 1)
+  for (int g = 0; g < G; ++g) v[g] = -INFINITY;
+  for (int i0 = 0; i0 < n; i0 += 64 * G)
 #pragma unroll
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      const float o = __shfl_xor(v, j);
-      v = (((lane & j) == 0) == ((lane & k) == 0)) ? fmaxf(v, o) : fminf(v, o);
+    for (int g = 0; g < G; ++g) {
+      const int i = i0 + 64 * g + lane;
+      if (i < n) v[g] = fmaxf(v[g], cs[i]);
     }
-  const float t = __shfl(v, kk - 1);
+  // keys in unsigned order; the kk-th largest by bisection over the 32 key bits (counts by ballot)
+  unsigned u[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const unsigned bits = __float_as_uint(v[g]);
+    u[g] = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
+  }
+  unsigned res = 0;
+#pragma unroll 1
+  for (int bit = 31; bit >= 0; --bit) {
+    const unsigned cand = res | (1u << bit);
+    int cnt = 0;
+#pragma unroll
+    for (int g = 0; g < G; ++g) cnt += __popcll(__ballot(u[g] >= cand));
+    if (cnt >= kk) res = cand;
+  }
+  // fewer than kk keys at all (a store smaller than kk rows): res stays 0, below every key
+  const unsigned rb = (res & 0x80000000u) ? (res & 0x7fffffffu) : ~res;
+  const float t = res == 0 ? -INFINITY : __uint_as_float(rb);
   if (lane == 0) { thr_out[q] = t; cand_cnt[q * kMfCntStride] = 0; }
 }
 #endif
