@@ -84,12 +84,10 @@ __global__ __launch_bounds__(1024) void select_kth_kernel(const float* __restric
   }
 }
 
-// Cheap valid threshold from the dense sample, one wave per query: lane l takes the maximum of the scores
-// l, l+64, l+128, ...; the kk-th largest of the 64 lane maxima (kk <= 64) is the score of an actual sampled
-// row with at least kk sampled rows at or above it, hence <= the true k'-th best.  A little looser than the
-// exact k'-th best of the sample (1.5 % instead of 1 % of the next pass's scores pass at kk = 40 over 4096
-// rows) but 10x cheaper than an exact selection over the dense scores (127 us at B = 1024).
-// Also clears the query's append counter for the first append pass.
+// Cheap valid threshold from the dense sample, one wave per query: the kk-th largest of strided group maxima is the
+// score of an actual sampled row with at least kk sampled rows at or above it, hence <= the true k'-th best.  A little
+// looser than the exact k'-th best of the sample but ~10x cheaper than an exact selection over the dense scores
+// (127 us at B = 1024).  Also clears the query's append counter for the first append pass.
 __global__ __launch_bounds__(64) void dense_lower_bound_kernel(const float* __restrict__ scores, int ld, int n, int kk,
                                                                float* __restrict__ thr_out, int* __restrict__ cand_cnt) {
   // kk-th largest of 256 strided group maxima (4 per lane; groups of 16 at n = 4096): about 1.06 % of a query's scores
