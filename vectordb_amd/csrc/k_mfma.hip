@@ -23,6 +23,11 @@ MfGrid mf_grid(int n_cu, int n_qt, long long pass_tiles, int max_splits) {
 
 static_assert(kMfDenseLdC == kMf3DenseLd && kMfRowBytesC == kMfRowBytes && kMfCntStrideC == kMfCntStride, "launch.h mirrors the kernels' constants");
 
+// waves per query in select_kth_kernel: 16 (one 1024-thread block per query, two per CU at a time) 11.63 / 1.669 ms per
+// 1024-query batch at 10M / 1.25M rows, 8 waves 11.59 / 1.647, 4 waves 11.57 / 1.642 (three libraries alternated on one box)
+#ifndef VDB_SEL_WAVES
+#define VDB_SEL_WAVES 4
+#endif
 #define MF_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return e_; } while (0)
 
 }  // namespace
@@ -124,7 +129,8 @@ hipError_t mfma_search_launch(const MfSearchArgs& a, int* skipped_tiles) {
     if (pass_tiles > 0) MF_TRY(launch_pass(1, pass_tiles, stride, skip_n));
     // the sample pass of a two-pass search keeps its sorted list when the last pass can leave its tiles out
     const bool keep = !last && n_pass == 2 && stride >= 2 && a.skip_sample;
-    hipLaunchKernelGGL(select_kth_kernel, dim3(b), dim3(1024), 0, st, (const float*)cand_s, (const int*)cand_i,
+    constexpr int kSelWaves = VDB_SEL_WAVES;
+    hipLaunchKernelGGL(select_kth_kernel<kSelWaves>, dim3(b), dim3(kSelWaves * 64), 0, st, (const float*)cand_s, (const int*)cand_i,
                        cand_cnt, last ? 0 : 1, cap, kk, thr, (last || keep) ? (last ? a.list_s : a.seed_s) : (float*)nullptr,
                        (last || keep) ? (last ? a.list_i : a.seed_i) : (int*)nullptr, ovf,
                        (last && seeded) ? (const float*)a.seed_s : (const float*)nullptr,

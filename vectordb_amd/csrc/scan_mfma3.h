@@ -35,14 +35,17 @@ constexpr int kMf3DenseLd = kMf3DenseTiles * kMfBM;
 // an append buffer with cand_cnt[q] entries (capacity cap; more -> *overflow = 1), optionally merged with a
 // seed list (seed_*).
 // zero_cnt != 0: the query's append counter is cleared for the next pass once every thread has read it.
-__global__ __launch_bounds__(1024) void select_kth_kernel(const float* __restrict__ cand_s, const int* __restrict__ cand_i,
+// NW waves per query: the kernel is a chain of wave sorts and merges (latency, not bandwidth), so what counts is how many
+// queries a CU holds at once and how deep the merge tree is - see the launch site for the measured choice.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void select_kth_kernel(const float* __restrict__ cand_s, const int* __restrict__ cand_i,
                                                           int* cand_cnt, int zero_cnt, int cap_or_n, int kk,
                                                           float* __restrict__ thr_out, float* __restrict__ list_s,
                                                           int* __restrict__ list_i, int* __restrict__ overflow,
                                                           const float* __restrict__ seed_s = nullptr,
                                                           const int* __restrict__ seed_i = nullptr) {
-  __shared__ float ls[8 * 64];
-  __shared__ int li[8 * 64];
+  __shared__ float ls[(NW / 2) * 64];
+  __shared__ int li[(NW / 2) * 64];
   const int q = blockIdx.x;
   const int w = threadIdx.x >> 6;
   const int lane = lane_id();
@@ -56,7 +59,7 @@ __global__ __launch_bounds__(1024) void select_kth_kernel(const float* __restric
   const int* ci = cand_i ? cand_i + (size_t)q * cap_or_n : nullptr;
   WaveTopK<1> tk;
   tk.init(kk);
-  for (int base = w * 64; base < n; base += 1024) {
+  for (int base = w * 64; base < n; base += NW * 64) {
     const int i = base + lane;
     const bool valid = i < n;
     const float s = valid ? cs[i] : -INFINITY;
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(1024) void select_kth_kernel(const float* __restric
   {
     const int lanei = lane;
 #pragma unroll
-    for (int half = 8; half >= 1; half >>= 1) {
+    for (int half = NW / 2; half >= 1; half >>= 1) {
       if (w >= half && w < 2 * half) { ls[(w - half) * 64 + lanei] = tk.s[0]; li[(w - half) * 64 + lanei] = tk.id[0]; }
       __syncthreads();
       if (w < half) tk.merge_sorted(ls[w * 64 + lanei], li[w * 64 + lanei]);
