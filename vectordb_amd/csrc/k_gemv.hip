@@ -1,6 +1,7 @@
 // k_gemv.hip — instantiations of the HBM-bound scan kernel (scan_gemv.h) and their dispatch.
 #include "launch.h"
 #include "scan_gemv.h"
+#include "scan_fused.h"
 
 namespace vdbk {
 namespace {
@@ -54,6 +55,31 @@ bool launch_scan_generic(const ScanArgs& a, int ld, int e, bool nt) {
 bool launch_scan_fast(bool bf16, int dim, const ScanArgs& a, int qb, int e, bool nt) {
   if (dim == 768) return bf16 ? launch_scan_dim<bf16_t, 768>(a, qb, e, nt) : launch_scan_dim<float, 768>(a, qb, e, nt);
   if (dim == 384) return bf16 ? launch_scan_dim<bf16_t, 384>(a, qb, e, nt) : launch_scan_dim<float, 384>(a, qb, e, nt);
+  return false;
+}
+
+namespace {
+template <typename T, int DIM, int QB>
+void launch_fused_t(const FusedScanArgs& a, bool nt, int grid, hipStream_t st) {
+  const size_t smem = fused_smem_bytes<DIM>(QB, a.kk);
+  if (nt) hipLaunchKernelGGL((scan_topk_fused_kernel<T, DIM, QB, true>), dim3(grid), dim3(kScanThreads), smem, st, a);
+  else hipLaunchKernelGGL((scan_topk_fused_kernel<T, DIM, QB, false>), dim3(grid), dim3(kScanThreads), smem, st, a);
+}
+template <typename T, int DIM>
+bool launch_fused_dim(const FusedScanArgs& a, int qb, bool nt, int grid, hipStream_t st) {
+  switch (qb) {
+    case 1: launch_fused_t<T, DIM, 1>(a, nt, grid, st); return true;
+    case 2: launch_fused_t<T, DIM, 2>(a, nt, grid, st); return true;
+    case 4: launch_fused_t<T, DIM, 4>(a, nt, grid, st); return true;
+  }
+  return false;
+}
+}  // namespace
+
+bool launch_scan_fused(bool bf16, int dim, const FusedScanArgs& a, int qb, bool nt, int grid, hipStream_t st) {
+  if (a.kk < 1 || a.kk > 64 || grid < 1 || grid > kFusedMaxParts || (a.kks & 3) || a.kks < a.kk) return false;
+  if (dim == 768) return bf16 ? launch_fused_dim<bf16_t, 768>(a, qb, nt, grid, st) : launch_fused_dim<float, 768>(a, qb, nt, grid, st);
+  if (dim == 384) return bf16 ? launch_fused_dim<bf16_t, 384>(a, qb, nt, grid, st) : launch_fused_dim<float, 384>(a, qb, nt, grid, st);
   return false;
 }
 

@@ -20,6 +20,32 @@ bool launch_scan_fast(bool bf16, int dim, const ScanArgs& a, int qb, int e, bool
 // any padded row length ld, one query per pass
 bool launch_scan_any(bool bf16, const ScanArgs& a, int ld, int e, bool nt);
 
+// the whole search of <= 4 queries with k' <= 64 in one launch (scan_fused.h): normalise, scan, fold, rerank, rank
+struct FusedScanArgs {
+  const void* rows; int n_rows;
+  const float* q;            // [qb][dim] queries: raw (normalize != 0) or already unit vectors
+  int normalize;
+  int kk, k, kks;            // k' (list length), k (outputs), list stride in the partial buffers (kk rounded up to 4)
+  int self0; const unsigned* allow;
+  float* part_s; int* part_i;      // [qb][grid][kks]
+  unsigned* ticket;                // kFusedTicketBytes, zero before the first launch: the arrival counter (the last arriver resets it), and
+                                   // on lines of their own the per-class scan-time sums and the class shares that tune themselves
+  int balance;                     // != 0: deal each group of blocks (same XCD, same turn on its CU) a range of tiles by its self-tuned share
+  int n_cu;                        // compute units of the device (blocks beyond the first n_cu are a CU's second, third, ... block)
+  int rerank; const float* rows_f32; const uint16_t* rows_b16;   // fp32 copy (or nullptr: re-score against the bf16 rows)
+  long long row_offset;
+  long long* out_idx; float* out_dist;   // [qb][k]
+  long long* stamps;               // diagnostic (option "scan_stamps"): 100 MHz clock stamps, [16] of the last block + [grid][6]; else nullptr
+};
+constexpr int kFusedTicketBytes = 512;
+constexpr int kFusedMaxRounds = 4;          // block groups: 8 XCD classes x up to 4 rounds of blocks over the CUs
+constexpr int kFusedDurOffset = 32;         // unsigneds from the ticket: [32] sums of block scan times (100 MHz ticks) per group
+constexpr int kFusedShareOffset = 64;       // [32] group shares (0 = not tuned yet = kFusedShareUnit)
+constexpr int kFusedShareUnit = 1024;
+constexpr int kFusedMaxParts = 1024;        // lists per query (= scan blocks) the fused epilogue covers
+// dim 768 or 384, qb in {1,2,4}, k' <= 64, grid <= kFusedMaxParts; false = no such instantiation
+bool launch_scan_fused(bool bf16, int dim, const FusedScanArgs& a, int qb, bool nt, int grid, hipStream_t st);
+
 // ---- k_mfma.hip: the batched bf16 path (scan_mfma{,3,4,5}.h) ----------------------------------
 // One batched search over device-resident, normalised fp32 queries: dense sample -> thresholds -> append
 // passes -> exact top-k' lists (list_*), with the exact list kernel as the device-flagged overflow fallback

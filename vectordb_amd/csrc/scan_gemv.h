@@ -64,7 +64,8 @@ __device__ __forceinline__ float chunk_dot<bf16_t>(const u32x4 v, const float* q
 // out layout [q][part][kk].
 template <int QB, int E>
 __device__ __forceinline__ void block_merge_store(WaveTopK<E> (&tk)[QB], int kk, float* __restrict__ part_s,
-                                                  int* __restrict__ part_i, int n_parts, int part) {
+                                                  int* __restrict__ part_i, int n_parts, int part, int stride = 0) {
+  if (stride == 0) stride = kk;   // floats between two lists of the output (>= kk)
   extern __shared__ __align__(16) unsigned char smem_raw[];
   float* ls = reinterpret_cast<float*>(smem_raw);          // [waves][QB][kk]
   int* li = reinterpret_cast<int*>(ls + kScanWaves * QB * kk);
@@ -93,7 +94,7 @@ __device__ __forceinline__ void block_merge_store(WaveTopK<E> (&tk)[QB], int kk,
           }
         }
       }
-      tk[q].store(part_s + ((size_t)q * n_parts + part) * kk, part_i + ((size_t)q * n_parts + part) * kk);
+      tk[q].store(part_s + ((size_t)q * n_parts + part) * stride, part_i + ((size_t)q * n_parts + part) * stride);
     }
   }
 }
@@ -106,25 +107,113 @@ __device__ __forceinline__ void block_merge_store(WaveTopK<E> (&tk)[QB], int kk,
 //             a tile's rows lie in one 32-bit word, fetched with the tile's loads
 //   part_*  : [QB][gridDim.x][kk] partial lists
 // ---------------------------------------------------------------------------
+// Geometry of the fast path: a wave-load group covers R whole rows with L loads; U groups make a tile.
+template <typename T, int DIM>
+struct ScanGeom {
+  static constexpr int EPC = ElemTraits<T>::kPerChunk;   // elements per 16-byte chunk
+  static constexpr int CPR = DIM / EPC;                  // chunks per row
+  static constexpr int G = cgcd(CPR, 64);
+  static constexpr int L = CPR / G;                      // wave-loads per group
+  static constexpr int R = 64 / G;                       // rows per group
+  static constexpr int U = (L >= kScanLoadsInFlight) ? 1 : (kScanLoadsInFlight / L);     // groups per tile
+  static constexpr int RPT = U * R;                      // rows per tile
+  static_assert(DIM % EPC == 0, "row must be a whole number of 16-byte chunks");
+  static_assert(RPT <= 32 && 32 % RPT == 0, "a tile's eligibility bits must lie in one word");
+};
+
+// One tile (RPT rows) of the corpus pass: all its loads at once, then the dots, the wave reductions and the insertions.
+template <typename T, int DIM, int QB, int E, bool NT>
+__device__ __forceinline__ void scan_one_tile(const u32x4* __restrict__ rows, int n_rows, long long total_chunks, long long tile, unsigned elig,
+                                              const float (&qreg)[QB][ScanGeom<T, DIM>::L][ScanGeom<T, DIM>::EPC],
+                                              WaveTopK<E> (&tk)[QB], int self0) {
+  using GM = ScanGeom<T, DIM>;
+  constexpr int CPR = GM::CPR, L = GM::L, R = GM::R, U = GM::U, RPT = GM::RPT;
+  const int lane = lane_id();
+  const long long c0 = tile * (long long)(RPT * CPR) + lane;
+  const long long row0 = tile * RPT;
+  u32x4 v[U * L];
+  if ((tile + 1) * RPT <= (long long)n_rows) {
+#pragma unroll
+    for (int t = 0; t < U * L; ++t) v[t] = load_chunk<NT>(rows + c0 + t * 64);
+  } else {
+#pragma unroll
+    for (int t = 0; t < U * L; ++t) {
+      const long long c = c0 + t * 64;
+      v[t] = (c < total_chunks) ? load_chunk<NT>(rows + c) : u32x4{0u, 0u, 0u, 0u};
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+#pragma unroll
+    for (int q = 0; q < QB; ++q) {
+      float p[L];
+#pragma unroll
+      for (int j = 0; j < L; ++j) p[j] = chunk_dot<T>(v[u * L + j], qreg[q][j]);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < L; ++j) {
+          // lanes of load j that belong to row r of the group: [lo, hi)
+          const int lo = r * CPR - j * 64, hi = lo + CPR;
+          if (lo <= 0 && hi >= 64) acc += p[j];
+          else if (hi <= 0 || lo >= 64) { /* no lane */ }
+          else acc += (lane >= lo && lane < hi) ? p[j] : 0.f;
+        }
+        const float tot = wave_sum(acc);
+        const long long row = row0 + u * R + r;
+        if (row < (long long)n_rows && ((elig >> (u * R + r)) & 1u)) {
+          const int ri = (int)row;
+          const bool self = (self0 >= 0) && (ri == self0 + q);
+          if (!self && tk[q].accepts(tot, ri)) tk[q].insert(tot, ri);
+        }
+      }
+    }
+  }
+}
+
+// The corpus pass of one wave: tiles t_begin + wid, t_begin + wid + nwv, ... below t_end, every one scored against the
+// QB queries in qreg, winners into tk.  The plain scan deals the whole corpus out over all waves of the grid
+// (t_begin = 0, wid = the wave's number in the grid); the fused kernel deals each class of blocks a range of its own
+// (scan_fused.h: the XCDs of an MI355X do not stream at one rate).
+template <typename T, int DIM, int QB, int E, bool NT>
+__device__ __forceinline__ void scan_corpus_tiles(const void* __restrict__ rows_v, int n_rows,
+                                                  const float (&qreg)[QB][ScanGeom<T, DIM>::L][ScanGeom<T, DIM>::EPC],
+                                                  WaveTopK<E> (&tk)[QB], int self0, const unsigned* __restrict__ allow,
+                                                  long long t_begin, long long t_end, long long wid, long long nwv) {
+  using GM = ScanGeom<T, DIM>;
+  constexpr int CPR = GM::CPR, RPT = GM::RPT;
+  const u32x4* __restrict__ rows = reinterpret_cast<const u32x4*>(rows_v);
+  const long long total_chunks = (long long)n_rows * CPR;
+  const long long first = t_begin + wid;
+
+  // eligibility bits of a tile's rows (bit j = row tile*RPT + j), fetched ONE TILE AHEAD so that the (wave-uniform)
+  // load hides behind the current tile; a tile with no eligible row is not read at all, so a selective where=
+  // filter streams only the tiles it needs (1 % eligible at random: 92 % of the 8-row tiles are skipped)
+  constexpr unsigned kTileBits = RPT == 32 ? 0xffffffffu : ((1u << RPT) - 1u);
+  auto tile_bits = [&](long long t) -> unsigned {
+    const long long r0 = t * RPT;
+    return (allow[r0 >> 5] >> (unsigned)(r0 & 31)) & kTileBits;
+  };
+  unsigned elig_next = (allow && first < t_end) ? tile_bits(first) : kTileBits;
+
+  for (long long tile = first; tile < t_end; tile += nwv) {
+    const unsigned elig = elig_next;
+    if (allow && tile + nwv < t_end) elig_next = tile_bits(tile + nwv);
+    if (elig == 0u) continue;
+    scan_one_tile<T, DIM, QB, E, NT>(rows, n_rows, total_chunks, tile, elig, qreg, tk, self0);
+  }
+}
+
 template <typename T, int DIM, int QB, int E, bool NT>
 __global__ __launch_bounds__(kScanThreads) void scan_topk_kernel(const void* __restrict__ rows_v, int n_rows,
                                                                   const float* __restrict__ qn, int kk,
                                                                   int self0, const unsigned* __restrict__ allow,
                                                                   float* __restrict__ part_s,
                                                                   int* __restrict__ part_i) {
-  constexpr int EPC = ElemTraits<T>::kPerChunk;   // elements per 16-byte chunk
-  constexpr int CPR = DIM / EPC;                  // chunks per row
-  constexpr int G = cgcd(CPR, 64);
-  constexpr int L = CPR / G;                      // wave-loads per group
-  constexpr int R = 64 / G;                       // rows per group
-  constexpr int U = (L >= kScanLoadsInFlight) ? 1 : (kScanLoadsInFlight / L);     // groups per tile
-  constexpr int RPT = U * R;                      // rows per tile
-  static_assert(DIM % EPC == 0, "row must be a whole number of 16-byte chunks");
-  static_assert(RPT <= 32 && 32 % RPT == 0, "a tile's eligibility bits must lie in one word");
-
-  const u32x4* __restrict__ rows = reinterpret_cast<const u32x4*>(rows_v);
+  using GM = ScanGeom<T, DIM>;
+  constexpr int EPC = GM::EPC, CPR = GM::CPR, L = GM::L;
   const int lane = lane_id();
-  const int w = threadIdx.x >> 6;
 
   // per-lane query slices: load j of a group covers chunk (j*64+lane) % CPR of its row
   float qreg[QB][L][EPC];
@@ -141,68 +230,9 @@ __global__ __launch_bounds__(kScanThreads) void scan_topk_kernel(const void* __r
 #pragma unroll
   for (int q = 0; q < QB; ++q) tk[q].init(kk);
 
-  const long long n_tiles = ((long long)n_rows + RPT - 1) / RPT;
-  const long long total_chunks = (long long)n_rows * CPR;
-  const long long gw = (long long)blockIdx.x * kScanWaves + w;
-  const long long nw = (long long)gridDim.x * kScanWaves;
-
-  // eligibility bits of a tile's rows (bit j = row tile*RPT + j), fetched ONE TILE AHEAD so that the (wave-uniform)
-  // load hides behind the current tile; a tile with no eligible row is not read at all, so a selective where=
-  // filter streams only the tiles it needs (1 % eligible at random: 92 % of the 8-row tiles are skipped)
-  constexpr unsigned kTileBits = RPT == 32 ? 0xffffffffu : ((1u << RPT) - 1u);
-  auto tile_bits = [&](long long t) -> unsigned {
-    const long long r0 = t * RPT;
-    return (allow[r0 >> 5] >> (unsigned)(r0 & 31)) & kTileBits;
-  };
-  unsigned elig_next = (allow && gw < n_tiles) ? tile_bits(gw) : kTileBits;
-
-  for (long long tile = gw; tile < n_tiles; tile += nw) {
-    const unsigned elig = elig_next;
-    if (allow && tile + nw < n_tiles) elig_next = tile_bits(tile + nw);
-    if (elig == 0u) continue;
-    const long long c0 = tile * (long long)(RPT * CPR) + lane;
-    const long long row0 = tile * RPT;
-    u32x4 v[U * L];
-    if ((tile + 1) * RPT <= (long long)n_rows) {
-#pragma unroll
-      for (int t = 0; t < U * L; ++t) v[t] = load_chunk<NT>(rows + c0 + t * 64);
-    } else {
-#pragma unroll
-      for (int t = 0; t < U * L; ++t) {
-        const long long c = c0 + t * 64;
-        v[t] = (c < total_chunks) ? load_chunk<NT>(rows + c) : u32x4{0u, 0u, 0u, 0u};
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-#pragma unroll
-      for (int q = 0; q < QB; ++q) {
-        float p[L];
-#pragma unroll
-        for (int j = 0; j < L; ++j) p[j] = chunk_dot<T>(v[u * L + j], qreg[q][j]);
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          float acc = 0.f;
-#pragma unroll
-          for (int j = 0; j < L; ++j) {
-            // lanes of load j that belong to row r of the group: [lo, hi)
-            constexpr int dummy = 0; (void)dummy;
-            const int lo = r * CPR - j * 64, hi = lo + CPR;
-            if (lo <= 0 && hi >= 64) acc += p[j];
-            else if (hi <= 0 || lo >= 64) { /* no lane */ }
-            else acc += (lane >= lo && lane < hi) ? p[j] : 0.f;
-          }
-          const float tot = wave_sum(acc);
-          const long long row = row0 + u * R + r;
-          if (row < (long long)n_rows && ((elig >> (u * R + r)) & 1u)) {
-            const int ri = (int)row;
-            const bool self = (self0 >= 0) && (ri == self0 + q);
-            if (!self && tk[q].accepts(tot, ri)) tk[q].insert(tot, ri);
-          }
-        }
-      }
-    }
-  }
+  constexpr int RPT = GM::RPT;
+  scan_corpus_tiles<T, DIM, QB, E, NT>(rows_v, n_rows, qreg, tk, self0, allow, 0, ((long long)n_rows + RPT - 1) / RPT,
+                                       (long long)blockIdx.x * kScanWaves + (threadIdx.x >> 6), (long long)gridDim.x * kScanWaves);
   block_merge_store<QB, E>(tk, kk, part_s, part_i, gridDim.x, blockIdx.x);
 }
 

@@ -4,6 +4,7 @@
 // all-gather.
 #pragma once
 #include "scan_gemv.h"
+#include "select_dev.h"
 
 namespace vdbk {
 
@@ -39,43 +40,6 @@ __global__ __launch_bounds__(kMergeThreads) void merge_lists_kernel(const float*
                           gridDim.x, blockIdx.x);
 }
 
-// ---- kk <= 64: every partial list is one sorted entry per lane -> bitonic folds ----
-// Fold lists [l0, l1) of one query (layout [list][kk]) into the wave's list.
-__device__ __forceinline__ void fold_sorted_lists(WaveTopK<1>& tk, const float* __restrict__ in_s,
-                                                  const int* __restrict__ in_i, int l0, int l1, int step, int kk) {
-  const int lane = lane_id();
-  const bool valid = lane < kk;
-  constexpr int kAhead = 8;  // issue the loads of up to 8 lists before the (dependent) merge chains
-  for (int l = l0; l < l1; l += kAhead * step) {
-    float cs[kAhead];
-    int ci[kAhead];
-#pragma unroll
-    for (int t = 0; t < kAhead; ++t) {
-      const int ll = l + t * step;
-      const bool ok = valid && ll < l1;
-      cs[t] = ok ? in_s[(size_t)ll * kk + lane] : -INFINITY;
-      ci[t] = ok ? in_i[(size_t)ll * kk + lane] : kIdxSentinel;
-    }
-#pragma unroll
-    for (int t = 0; t < kAhead; ++t)
-      if (l + t * step < l1) tk.merge_sorted(cs[t], ci[t]);  // wave-uniform
-  }
-}
-
-// Tree-merge the NW per-wave lists of a block through LDS; wave 0 ends with the result.
-template <int NW>
-__device__ __forceinline__ void block_tree_merge(WaveTopK<1>& tk, float* ls, int* li) {
-  const int w = threadIdx.x >> 6;
-  const int lane = lane_id();
-#pragma unroll
-  for (int half = NW / 2; half >= 1; half >>= 1) {
-    if (w >= half && w < 2 * half) { ls[(w - half) * 64 + lane] = tk.s[0]; li[(w - half) * 64 + lane] = tk.id[0]; }
-    __syncthreads();
-    if (w < half) tk.merge_sorted(ls[w * 64 + lane], li[w * 64 + lane]);
-    __syncthreads();
-  }
-}
-
 // Level-1 merge: block (256 threads) folds `lists_per_block` lists; out [q][gridDim.x][kk].
 __global__ __launch_bounds__(256) void merge_sorted_lists_kernel(const float* __restrict__ in_s,
                                                                  const int* __restrict__ in_i, int n_lists,
@@ -94,33 +58,6 @@ __global__ __launch_bounds__(256) void merge_sorted_lists_kernel(const float* __
   if (w == 0) tk.store(out_s + ((size_t)q * gridDim.x + blockIdx.x) * kk, out_i + ((size_t)q * gridDim.x + blockIdx.x) * kk);
 }
 
-__device__ __forceinline__ bool dist_better(float d, long long i, float od, long long oi) {
-  return (d < od) || (d == od && i < oi);
-}
-
-// Final ranking of one query's m candidates (score, local idx) held in LDS:
-// order by (distance asc, index asc) — the same key the cross-shard merge uses,
-// so results do not depend on the number of shards.  Writes k outputs.
-__device__ __forceinline__ void rank_and_write(const float* ls, const int* li, int m, int k, long long row_offset,
-                                               long long* __restrict__ out_idx, float* __restrict__ out_dist) {
-  for (int t = threadIdx.x; t < k; t += blockDim.x) { out_idx[t] = -1; out_dist[t] = INFINITY; }
-  __syncthreads();
-  for (int t = threadIdx.x; t < m; t += blockDim.x) {
-    const int id = li[t];
-    const float sc = ls[t];
-    if (id == kIdxSentinel || !(sc == sc)) continue;
-    const float d = 1.0f - sc;
-    int rank = 0;
-    for (int j = 0; j < m; ++j) {
-      const int oj = li[j];
-      const float sj = ls[j];
-      if (oj == kIdxSentinel || !(sj == sj)) continue;
-      rank += dist_better(1.0f - sj, oj, d, id) ? 1 : 0;
-    }
-    if (rank < k) { out_idx[rank] = (long long)id + row_offset; out_dist[rank] = d; }
-  }
-}
-
 // No-rerank finish: merged [b][kk] -> outputs [b][k].  LDS: kk*(4+4) bytes.
 __global__ __launch_bounds__(256) void finalize_kernel(const float* __restrict__ m_s, const int* __restrict__ m_i,
                                                        int kk, int k, long long row_offset,
@@ -133,16 +70,6 @@ __global__ __launch_bounds__(256) void finalize_kernel(const float* __restrict__
   for (int t = threadIdx.x; t < kk; t += blockDim.x) { ls[t] = m_s[(size_t)q * kk + t]; li[t] = m_i[(size_t)q * kk + t]; }
   __syncthreads();
   rank_and_write(ls, li, kk, k, row_offset, out_idx + (size_t)q * k, out_dist + (size_t)q * k);
-}
-
-// four consecutive elements j*4 .. j*4+3 of stored row `id`: from the fp32 copy, or (a store without one) from the bf16 rows
-__device__ __forceinline__ f32x4 stored_row4(const float* __restrict__ rows_f32, const uint16_t* __restrict__ rows_b16, int id, int ld, int j) {
-  if (rows_f32) return reinterpret_cast<const f32x4*>(rows_f32 + (size_t)id * ld)[j];
-  const uint2 u = reinterpret_cast<const uint2*>(rows_b16 + (size_t)id * ld)[j];
-  f32x4 r;
-  r.x = __uint_as_float(u.x << 16); r.y = __uint_as_float(u.x & 0xffff0000u);
-  r.z = __uint_as_float(u.y << 16); r.w = __uint_as_float(u.y & 0xffff0000u);
-  return r;
 }
 
 // fp32 rerank: exact fp32 dot of the query with each of the kk candidate rows
@@ -286,7 +213,7 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __rest
   for (long long r = w; r < n; r += nw) {
     const float* x = in + r * in_ld;
     double ss = 0.0;
-    for (int c = lane; c < dim; c += 64) { const double v = (double)x[c]; ss += v * v; }
+    for (int c = lane; c < dim; c += 64) { const double v = (double)x[c]; ss = fma(v, v, ss); }   // scan_fused.h's prologue does the same
     ss = wave_sum_f64(ss);
     const double inv = 1.0 / (sqrt(ss) + 1e-30);
     for (int c = lane; c < ld; c += 64) {

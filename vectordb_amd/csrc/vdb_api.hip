@@ -45,7 +45,9 @@ constexpr int kNaMaxLd = 4096;      // padded row length
 constexpr size_t kNaQBytes = (size_t)kNaMaxB * kNaMaxLd * 4;                               // 128 KiB
 constexpr size_t kNaPartElems = (size_t)kNaMaxB * kNaMaxGrid * kNaMaxKK;                  // 1 MiB per array
 constexpr size_t kNaPart2Elems = (size_t)kNaMaxB * ((kNaMaxGrid + 31) / 32) * kNaMaxKK;   // after one 32-way fold
-constexpr size_t kNaScratchBytes = kNaQBytes + 8 * kNaPartElems + 8 * kNaPart2Elems;
+constexpr size_t kNaListBytes = kNaQBytes + 8 * kNaPartElems + 8 * kNaPart2Elems;
+constexpr size_t kNaScratchBytes = kNaListBytes + 512;   // + the fused kernel's ticket and work-pool heads (kFusedTicketBytes; zero at load; its last block resets them)
+static_assert(kFusedTicketBytes <= 512, "ticket area");
 static __device__ __align__(256) unsigned char scratch[kNaScratchBytes];
 
 constexpr int kMaxDevices = 64;
@@ -101,6 +103,10 @@ struct vdb {
   int mfma_last_b = 0;           // batch size of the last MFMA search (locates its overflow flag)
   int mfma_last_skipped = 0;     // tiles the last MFMA search's final pass left out (the sample pass's)
   int mfma_force_fallback = 0;   // test hook: route through the exact list kernel
+  int scan_balance = 1;          // the fused kernel deals its tiles out by self-tuning per-XCD shares (XCDs stream at different rates)
+  int fuse_small = 1;            // <= 4 queries with k' <= 64 on the fast dims: normalise + scan + fold + rerank in ONE launch (scan_fused.h)
+  DevBuf w_stamps;               // diagnostic: clock stamps of the fused kernel (option "scan_stamps")
+  DevBuf w_ticket;               // the fused kernel's arrival counter: zeroed at create, reset by the kernel's last block
   void* na_scratch = nullptr;    // this device's copy of `scratch` (hipGetSymbolAddress at create)
   // ---- sharded handle (vdb_create_sharded): a router over per-device shards; none of the fields above but
   // dim/ld/dtype/keep_f32/device(= shard 0's)/stream/pin/w_stage/w_out_i/w_gather are used on it
@@ -369,6 +375,8 @@ bool mfma_is_faster(int b, int n_rows, int variant_opt) {
 
 constexpr int kQChunk = 64;   // queries per scan/merge round of the GEMV path
 
+bool fast_dim(const vdb_t* h) { return (h->ld == h->dim) && (h->dim == 768 || h->dim == 384); }
+
 // grid: enough blocks to fill the chip, never more tiles than work
 int gemv_grid(vdb_t* h) {
   const int rows_per_block_min = 64;
@@ -392,11 +400,11 @@ int gemv_scan_chunk(vdb_t* h, const WsPtrs& W, const float* qn, int cb, int kk, 
   const bool bf16 = h->dtype == VDB_BF16;
   const void* rows = bf16 ? (const void*)h->rows_bf16 : (const void*)h->rows_f32;
   const int n_rows = (int)h->n;
-  const bool fast_dim = (h->ld == h->dim) && (h->dim == 768 || h->dim == 384);
+  const bool fast = fast_dim(h);
   int q = 0;
   while (q < cb) {
     int qb = 1;
-    if (fast_dim && e <= 2) { if (cb - q >= 4) qb = 4; else if (cb - q >= 2) qb = 2; }
+    if (fast && e <= 2) { if (cb - q >= 4) qb = 4; else if (cb - q >= 2) qb = 2; }
     ScanArgs a;
     a.rows = rows; a.n_rows = n_rows; a.qn = qn + (size_t)q * h->ld; a.kk = kk;
     a.self0 = self_row0 >= 0 ? (int)(self_row0 + q) : -1;
@@ -407,7 +415,7 @@ int gemv_scan_chunk(vdb_t* h, const WsPtrs& W, const float* qn, int cb, int kk, 
     a.smem = (size_t)4 * qb * kk * 8;   // 4 waves per scan block
     bool ok;
     const bool nt = h->scan_nt_loads != 0;
-    if (fast_dim) {
+    if (fast) {
       ok = launch_scan_fast(bf16, h->dim, a, qb, e, nt);
     } else {
       a.smem = (size_t)4 * kk * 8 + (size_t)h->ld * 4;
@@ -430,11 +438,44 @@ bool takes_mfma_path(vdb_t* h, int b, int kk, int kp, bool masked) {
          h->n >= 4096 && (!h->mfma_cost_model || mfma_is_faster(b, (int)h->n, h->mfma_variant));
 }
 
-// Core search over device-resident, already *normalised* queries qn [b][ld].
+// Is this GEMV-path batch served by the fused kernel (scan_fused.h: one launch per <= 4 queries)?
+bool fuses(vdb_t* h, int b, int kk) {
+  return h->fuse_small && b <= 4 && kk <= 64 && fast_dim(h) && gemv_grid(h) <= kFusedMaxParts;
+}
+
+// The fused launches of b <= 4 queries (4, 2 or 1 per corpus pass): q are raw queries (q_raw: the kernel normalises
+// them in its prologue) or unit vectors; each launch writes its queries' k results itself.
+int gemv_fused(vdb_t* h, const WsPtrs& W, unsigned* ticket, const float* q, bool q_raw, int b, int kk, int k, int kp,
+               int64_t self_row0, const unsigned* allow, int grid, int64_t* out_idx, float* out_dist, hipStream_t st) {
+  const bool bf16 = h->dtype == VDB_BF16;
+  for (int qd = 0; qd < b;) {
+    const int qb = b - qd >= 4 ? 4 : b - qd >= 2 ? 2 : 1;
+    FusedScanArgs a;
+    a.rows = bf16 ? (const void*)h->rows_bf16 : (const void*)h->rows_f32; a.n_rows = (int)h->n;
+    a.q = q + (size_t)qd * h->ld; a.normalize = q_raw ? 1 : 0;
+    a.kk = kk; a.k = k; a.kks = round_up(kk, 4);
+    a.self0 = self_row0 >= 0 ? (int)(self_row0 + qd) : -1; a.allow = allow;
+    a.part_s = W.ps; a.part_i = W.pi;          // the next launch reuses them (stream order)
+    a.ticket = ticket; a.balance = h->scan_balance; a.n_cu = h->n_cu;
+    a.rerank = kp != 0; a.rows_f32 = h->keep_f32 ? h->rows_f32 : nullptr; a.rows_b16 = h->rows_bf16;
+    a.row_offset = (long long)h->row_offset;
+    a.out_idx = (long long*)out_idx + (size_t)qd * k; a.out_dist = out_dist + (size_t)qd * k;
+    a.stamps = (long long*)h->w_stamps.p;
+    if (!launch_scan_fused(bf16, h->dim, a, qb, h->scan_nt_loads != 0, grid, st)) return fail(h, VDB_ERR_ARG, "search: unsupported shape for the fused scan");
+    HIP_TRY(h, hipGetLastError());
+    h->last_bytes += (double)h->n * h->ld * (bf16 ? 2 : 4);
+    h->last_passes++;
+    qd += qb;
+  }
+  return VDB_OK;
+}
+
+// Core search over device-resident queries qn [b][ld]: already *normalised*, or (q_raw, only where will_fuse()
+// says so) raw.
 // self_row0 >= 0: query q excludes row self_row0+q.
 // allow != nullptr: device bitmap of eligible rows (GEMV scan only).
 int search_core(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_row0, int64_t* out_idx,
-                float* out_dist, hipStream_t st, const unsigned* allow = nullptr) {
+                float* out_dist, hipStream_t st, const unsigned* allow = nullptr, bool q_raw = false) {
   const int kk = kp ? kp : k;
   const int n_rows = (int)h->n;
   // slot 0 of the two-phase search shares these workspaces: a scan pending there would be overwritten
@@ -476,6 +517,13 @@ int search_core(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
 
   const int grid = gemv_grid(h);
   const WsSet W = ws_of(h, 0);
+  if (fuses(h, b, kk)) {
+    if ((rc = ensure_parts(h, W, (size_t)std::min(b, 4) * grid * round_up(kk, 4)))) return rc;
+    if ((rc = gemv_fused(h, ptrs_of(W), (unsigned*)h->w_ticket.p, qn, q_raw, b, kk, k, kp, self_row0, allow, grid, out_idx, out_dist, st))) return rc;
+    if (h->ev_on) { HIP_TRY(h, hipEventRecord(h->ev[1], st)); HIP_TRY(h, hipEventRecord(h->ev[2], st)); h->timing_valid = true; }
+    return VDB_OK;
+  }
+  if (q_raw) return fail(h, VDB_ERR_STATE, "search: internal: raw queries on an unfused path");
   // queries are processed in chunks so the partial buffers stay small
   const int cb_max = std::min(b, kQChunk);
   if ((rc = ensure_parts(h, W, (size_t)cb_max * grid * kk))) return rc;
@@ -523,6 +571,21 @@ int prep_queries(vdb_t* h, const float* q_dev, int b, hipStream_t st, float** qn
   return VDB_OK;
 }
 
+// The queries search_core gets: normalised into the workspace, or — where the fused kernel will serve the batch and
+// normalises in its own prologue — the caller's raw ones as they are.
+bool will_fuse(vdb_t* h, int b, int k, int kp, bool masked) {
+  const int kk = kp ? kp : k;
+  return h->n > 0 && !takes_mfma_path(h, b, kk, kp, masked) && fuses(h, b, kk);
+}
+int prep_or_pass(vdb_t* h, const float* q_dev, int b, int k, int kp, bool masked, hipStream_t st, const float** q_out, bool* raw) {
+  *raw = will_fuse(h, b, k, kp, masked);
+  if (*raw) { *q_out = q_dev; return VDB_OK; }
+  float* qn = nullptr;
+  const int rc = prep_queries(h, q_dev, b, st, &qn);
+  *q_out = qn;
+  return rc;
+}
+
 }  // namespace
 
 // ===========================================================================
@@ -550,6 +613,11 @@ int vdb_create(vdb_t** out, int dim, int dtype, int keep_f32, int device_id) {
   }
   h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (resize_ring(h, 1) != VDB_OK) { vdb_destroy(h); return fail(nullptr, VDB_ERR_DEVICE, "vdb_create: event creation failed"); }
+  if (hipMalloc(&h->w_ticket.p, kFusedTicketBytes) != hipSuccess || hipMemset(h->w_ticket.p, 0, kFusedTicketBytes) != hipSuccess) {
+    vdb_destroy(h);
+    return fail(nullptr, VDB_ERR_MEMORY, "vdb_create: no device memory for the arrival counter");
+  }
+  h->w_ticket.bytes = kFusedTicketBytes;
   // this device's copy of the no-allocation entry point's scratch array: its address is taken ONCE per device,
   // with the device current (set above); kernels only ever see this pointer, never the array's name
   if (device_id < kMaxDevices) {
@@ -615,7 +683,7 @@ void vdb_destroy(vdb_t* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
   if (h->ev_q) (void)hipEventDestroy(h->ev_q);
-  DevBuf* bufs[] = {&h->w_gather, &h->w_fb_s, &h->w_fb_i, &h->w_q1, &h->w_part_s1, &h->w_part_i1, &h->w_part2_s1, &h->w_part2_i1, &h->w_q, &h->w_part_s, &h->w_part_i, &h->w_part2_s, &h->w_part2_i, &h->w_stage, &h->w_out_i, &h->w_out_d, &h->w_idx, &h->w_mfma,
+  DevBuf* bufs[] = {&h->w_stamps, &h->w_ticket, &h->w_gather, &h->w_fb_s, &h->w_fb_i, &h->w_q1, &h->w_part_s1, &h->w_part_i1, &h->w_part2_s1, &h->w_part2_i1, &h->w_q, &h->w_part_s, &h->w_part_i, &h->w_part2_s, &h->w_part2_i, &h->w_stage, &h->w_out_i, &h->w_out_d, &h->w_idx, &h->w_mfma,
                     &h->w_cand_s, &h->w_cand_i, &h->w_cand_cnt, &h->w_thr, &h->w_dense, &h->w_list_s, &h->w_list_i, &h->w_mask, &h->w_seed_s, &h->w_seed_i};
   for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
   if (h->pin) (void)hipHostFree(h->pin);
@@ -748,8 +816,9 @@ int sharded_search_dev(vdb_t* h, const float* q_dev0, int b, int k, int kp, int6
       HIP_TRY(h, hipMemcpyPeerAsync(c->w_stage.p, c->device, q_dev0, h->device, (size_t)b * h->dim * 4, c->stream));
       q_local = (const float*)c->w_stage.p;
     }
-    float* qn = nullptr;
-    if ((rc = prep_queries(c, q_local, b, c->stream, &qn))) return fail(h, rc, c->err);
+    const float* qn = nullptr;
+    bool raw = false;
+    if ((rc = prep_or_pass(c, q_local, b, k, kp, false, c->stream, &qn, &raw))) return fail(h, rc, c->err);
     int64_t* oi = g_idx + (size_t)s * bk;
     float* od = g_dist + (size_t)s * bk;
     if (!h->shard_direct[(size_t)s]) {
@@ -757,7 +826,7 @@ int sharded_search_dev(vdb_t* h, const float* q_dev0, int b, int k, int kp, int6
       oi = (int64_t*)c->w_out_i.p;
       od = (float*)((char*)c->w_out_i.p + bk * 8);
     }
-    if ((rc = search_core(c, qn, b, k, kp, -1, oi, od, c->stream))) return fail(h, rc, c->err);
+    if ((rc = search_core(c, qn, b, k, kp, -1, oi, od, c->stream, nullptr, raw))) return fail(h, rc, c->err);
     if (!h->shard_direct[(size_t)s]) {
       HIP_TRY(h, hipMemcpyPeerAsync(g_idx + (size_t)s * bk, h->device, oi, c->device, bk * 8, c->stream));
       HIP_TRY(h, hipMemcpyPeerAsync(g_dist + (size_t)s * bk, h->device, od, c->device, bk * 4, c->stream));
@@ -782,9 +851,10 @@ int vdb_search_dev(vdb_t* h, const float* queries_dev, int b, int k, int kp, int
   if (is_sharded(h)) return sharded_search_dev(h, queries_dev, b, k, kp, out_idx_dev, out_dist_dev, (hipStream_t)stream);
   if ((rc = set_device(h))) return rc;
   hipStream_t st = (hipStream_t)stream;  // NULL = the default (null) stream, HIP convention
-  float* qn = nullptr;
-  if ((rc = prep_queries(h, queries_dev, b, st, &qn))) return rc;
-  return search_core(h, qn, b, k, kp, -1, out_idx_dev, out_dist_dev, st);
+  const float* qn = nullptr;
+  bool raw = false;
+  if ((rc = prep_or_pass(h, queries_dev, b, k, kp, false, st, &qn, &raw))) return rc;
+  return search_core(h, qn, b, k, kp, -1, out_idx_dev, out_dist_dev, st, nullptr, raw);
 }
 
 // vdb_search_dev for callers that cannot allocate (HIP graph capture, tight serving loops): the GEMV scan with
@@ -818,11 +888,13 @@ int vdb_search_dev_noalloc(vdb_t* h, const float* queries_dev, int b, int k, int
   P.pi = (int*)(base + kNaQBytes + 4 * kNaPartElems);
   P.p2s = (float*)(base + kNaQBytes + 8 * kNaPartElems);
   P.p2i = (int*)(base + kNaQBytes + 8 * kNaPartElems + 4 * kNaPart2Elems);
+  h->ev_on = false;               // no timing events on this path
+  h->last_bytes = 0.0; h->last_path = 0; h->last_passes = 0;
+  if (fuses(h, b, kk))            // one launch per <= 4 queries, its arrival counter in the same array
+    return gemv_fused(h, P, (unsigned*)(base + kNaListBytes), queries_dev, true, b, kk, k, kp, -1, nullptr, grid, out_idx_dev, out_dist_dev, st);
   const int blocks = std::max(1, std::min((b + 3) / 4, h->n_cu * 8));
   hipLaunchKernelGGL(normalize_rows_kernel, dim3(blocks), dim3(256), 0, st, queries_dev, h->dim, (long long)b, h->dim, h->ld, qn, (uint16_t*)nullptr);
   HIP_TRY(h, hipGetLastError());
-  h->ev_on = false;               // no timing events on this path
-  h->last_bytes = 0.0; h->last_path = 0; h->last_passes = 0;
   if ((rc = gemv_scan_chunk(h, P, qn, b, kk, -1, nullptr, grid, st))) return rc;
   return finish_search(h, P, b, grid, kk, k, kp, qn, out_idx_dev, out_dist_dev, st);
 }
@@ -917,9 +989,10 @@ int search_host(vdb_t* h, const float* queries_host, int b, int k, int kp, int64
   if (is_sharded(h)) {
     if ((rc = sharded_search_dev(h, (const float*)h->w_stage.p, b, k, kp, d_idx, d_dist, h->stream))) return rc;
   } else {
-    float* qn = nullptr;
-    if ((rc = prep_queries(h, (const float*)h->w_stage.p, b, h->stream, &qn))) return rc;
-    if ((rc = search_core(h, qn, b, k, kp, -1, d_idx, d_dist, h->stream))) return rc;
+    const float* qn = nullptr;
+    bool raw = false;
+    if ((rc = prep_or_pass(h, (const float*)h->w_stage.p, b, k, kp, false, h->stream, &qn, &raw))) return rc;
+    if ((rc = search_core(h, qn, b, k, kp, -1, d_idx, d_dist, h->stream, nullptr, raw))) return rc;
     if (rbytes) {
       const long long nr = (long long)b * k;
       hipLaunchKernelGGL(gather_result_rows_kernel, dim3((int)std::min<long long>((nr + 3) / 4, (long long)h->n_cu * 8)), dim3(256), 0, h->stream,
@@ -977,9 +1050,10 @@ int vdb_search_masked_dev(vdb_t* h, const float* queries_dev, int b, int k, int 
   if (b == 0) return VDB_OK;
   if ((rc = set_device(h))) return rc;
   hipStream_t st = (hipStream_t)stream;
-  float* qn = nullptr;
-  if ((rc = prep_queries(h, queries_dev, b, st, &qn))) return rc;
-  return search_core(h, qn, b, k, kp, -1, out_idx_dev, out_dist_dev, st, allow_dev);
+  const float* qn = nullptr;
+  bool raw = false;
+  if ((rc = prep_or_pass(h, queries_dev, b, k, kp, true, st, &qn, &raw))) return rc;
+  return search_core(h, qn, b, k, kp, -1, out_idx_dev, out_dist_dev, st, allow_dev, raw);
 }
 
 int vdb_search_masked(vdb_t* h, const float* queries_host, int b, int k, int kp, const uint32_t* allow_host,
@@ -999,10 +1073,11 @@ int vdb_search_masked(vdb_t* h, const float* queries_host, int b, int k, int kp,
   if ((rc = ensure(h, h->w_out_d, (size_t)b * k * 4))) return rc;
   if (words) HIP_TRY(h, hipMemcpyAsync(h->w_mask.p, allow_host, words * 4, hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipMemcpyAsync(h->w_stage.p, queries_host, (size_t)b * h->dim * 4, hipMemcpyHostToDevice, h->stream));
-  float* qn = nullptr;
-  if ((rc = prep_queries(h, (const float*)h->w_stage.p, b, h->stream, &qn))) return rc;
+  const float* qn = nullptr;
+  bool raw = false;
+  if ((rc = prep_or_pass(h, (const float*)h->w_stage.p, b, k, kp, true, h->stream, &qn, &raw))) return rc;
   if ((rc = search_core(h, qn, b, k, kp, -1, (int64_t*)h->w_out_i.p, (float*)h->w_out_d.p, h->stream,
-                        (const unsigned*)h->w_mask.p))) return rc;
+                        (const unsigned*)h->w_mask.p, raw))) return rc;
   HIP_TRY(h, hipMemcpyAsync(out_idx, h->w_out_i.p, (size_t)b * k * 8, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipMemcpyAsync(out_dist, h->w_out_d.p, (size_t)b * k * 4, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1386,6 +1461,17 @@ int vdb_set_option(vdb_t* h, const char* name, int64_t value) {
     h->mfma_append_cap = (int)value; return VDB_OK;
   }
   if (!strcmp(name, "mfma_cost_model")) { h->mfma_cost_model = value != 0; return VDB_OK; }
+  if (!strcmp(name, "fuse_small_batch")) { h->fuse_small = value != 0; return VDB_OK; }
+  if (!strcmp(name, "scan_balance")) { h->scan_balance = (int)std::max<int64_t>(0, std::min<int64_t>(value, 2)); return VDB_OK; }   // 0: every wave of the grid takes every nw-th tile
+  if (!strcmp(name, "scan_stamps")) {   // diagnostic: the fused kernel writes clock stamps (read back with get_stat "scan_stamp_<i>")
+    int rc = set_device(h);
+    if (rc) return rc;
+    HIP_TRY(h, hipDeviceSynchronize());
+    if (!value) { if (h->w_stamps.p) { HIP_TRY(h, hipFree(h->w_stamps.p)); h->w_stamps.p = nullptr; h->w_stamps.bytes = 0; } return VDB_OK; }
+    if ((rc = ensure(h, h->w_stamps, (size_t)(16 + 6 * kFusedMaxParts) * 8))) return rc;
+    HIP_TRY(h, hipMemset(h->w_stamps.p, 0, h->w_stamps.bytes));
+    return VDB_OK;
+  }
   if (!strcmp(name, "batch_mfma_min_b")) { if (value < 1) return fail(h, VDB_ERR_ARG, "batch_mfma_min_b must be >= 1"); h->batch_mfma_min_b = (int)std::min<int64_t>(value, 1 << 30); return VDB_OK; }
   return fail(h, VDB_ERR_ARG, std::string("set_option: unknown option ") + name);
 }
@@ -1468,6 +1554,31 @@ int vdb_get_stat(vdb_t* h, const char* name, int64_t* value) {
     return VDB_OK;
   }
   if (!strcmp(name, "mfma_last_skipped_tiles")) { *value = h->mfma_last_skipped; return VDB_OK; }
+  if (!strncmp(name, "scan_share_", 11)) {   // the fused scan's self-tuned share of block group g (1024 = equal)
+    const long g = strtol(name + 11, nullptr, 10);
+    if (g < 0 || g >= 8 * kFusedMaxRounds) return fail(h, VDB_ERR_ARG, "scan_share_<g>: g in [0, 32)");
+    int rc = set_device(h);
+    if (rc) return rc;
+    unsigned v = 0;
+    HIP_TRY(h, hipDeviceSynchronize());
+    HIP_TRY(h, hipMemcpy(&v, (unsigned*)h->w_ticket.p + kFusedShareOffset + g, 4, hipMemcpyDeviceToHost));
+    *value = v ? v : kFusedShareUnit;
+    return VDB_OK;
+  }
+  if (!strncmp(name, "scan_stamp_", 11)) {
+    const long i = strtol(name + 11, nullptr, 10);
+    if (!h->w_stamps.p || i < 0 || i >= 16 + 6 * kFusedMaxParts) return fail(h, VDB_ERR_ARG, "scan_stamp_<i>: set option scan_stamps first; i in [0, 6160)");
+    int rc = set_device(h);
+    if (rc) return rc;
+    static thread_local std::vector<long long> cache;   // one copy serves a run of reads: index 0 refreshes it
+    if (i == 0 || cache.empty()) {
+      cache.resize(16 + 6 * kFusedMaxParts);
+      HIP_TRY(h, hipDeviceSynchronize());
+      HIP_TRY(h, hipMemcpy(cache.data(), h->w_stamps.p, cache.size() * 8, hipMemcpyDeviceToHost));
+    }
+    *value = cache[(size_t)i];
+    return VDB_OK;
+  }
   if (!strcmp(name, "mfma_last_hits")) {   // candidates appended by the last (full) pass, summed over queries
     *value = 0;
     if (!h->w_cand_cnt.p || h->mfma_last_b <= 0) return VDB_OK;
