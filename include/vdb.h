@@ -82,8 +82,14 @@ int vdb_create(vdb_t** out, int dim, int dtype, int keep_f32_for_rerank, int dev
  * stream; each shard's finish kernel stores its k results straight into shard 0's gather buffer (over xGMI when peer
  * access is available, a peer copy otherwise) and one merge kernel on shard 0 ranks the n_devices lists.  No host
  * synchronisation inside vdb_search_dev; queries and outputs of the *_dev calls live on shard 0's device.
- * Served on a sharded handle: reserve, add, add_synth, count, search, search_fetch, search_dev, fetch, save, last_timing,
- * timing_stats, set_option (applied to every shard), get_stat.  Everything else returns VDB_ERR_STATE. */
+ * Shard 0 (it lives on the callers' device) runs on the CALLER's stream, the others on streams of their own behind one
+ * event each way; the host spends ~16 us per further shard on those runtime calls (profiles/r03_sharded_issue_cost.json).
+ * Served on a sharded handle: reserve, rebalance, warm, add, add_dev (rows on shard 0's device; each span goes to its
+ * shard, over a peer copy where that is another GPU), add_synth, count, search, search_fetch, search_dev, search_masked
+ * and search_masked_dev (the bitmap covers the GLOBAL rows; a shard's first row is a multiple of 256, so its slice is
+ * word-aligned), selfjoin (blocks of rows-as-queries cut at shard borders, searched like any batch), fetch, save,
+ * last_timing, timing_stats, set_option (applied to every shard), get_stat.  Not served (VDB_ERR_STATE):
+ * set_row_offset, the two-phase pair, search_dev_noalloc, merge_topk_dev. */
 int vdb_create_sharded(vdb_t** out, int dim, int dtype, int keep_f32_for_rerank, const int* device_ids, int n_devices);
 
 /* Replaces client.delete_collection(name) for the vector segment
@@ -98,6 +104,19 @@ const char* vdb_last_error(vdb_t* h);
  * counterpart (hnswlib's max_elements resize is internal to chromadb). */
 int vdb_reserve(vdb_t* h, int64_t n_rows);
 
+/* Re-partition a row-sharded handle for total_rows rows (no counterpart in the reference: chromadb's segment lives in
+ * one process' memory).  The stored rows move between the shards' GPUs as they are (device to device, verbatim bits),
+ * so a store that outgrew the partition its first vdb_reserve fixed — the last shard takes every row beyond it — is
+ * balanced again; searches return what they returned before.  Needs room for a second copy of each shard while it
+ * runs.  On a single store it is vdb_reserve.  The Chroma-shaped face calls it as a collection grows (doubling). */
+int vdb_rebalance(vdb_t* h, int64_t total_rows);
+
+/* Size every workspace that searches of up to max_batch queries with this k / rerank_kprime need on the store as it is
+ * now (one dummy search per kernel family on generated queries, results discarded), so that no later search of those
+ * shapes grows a workspace: a growth drains the device, frees and allocates inside the caller's search.  No counterpart
+ * in the reference.  Blocks until done. */
+int vdb_warm(vdb_t* h, int max_batch, int k, int rerank_kprime);
+
 /* Global index of this shard's row 0 (multi-GPU row sharding). */
 int vdb_set_row_offset(vdb_t* h, int64_t row_offset);
 
@@ -108,7 +127,7 @@ int vdb_set_row_offset(vdb_t* h, int64_t row_offset);
  * (cosine space) and stored fp32 and/or bf16. */
 int vdb_add(vdb_t* h, const float* rows_host, int64_t n);
 
-/* Same, rows already resident in device memory (embedder output, generator). */
+/* Same, rows already resident in device memory (embedder output, generator); on a sharded handle: on shard 0's device. */
 int vdb_add_dev(vdb_t* h, const float* rows_dev, int64_t n);
 
 /* Replaces collection.count() (tests/test_vectordb.py:101). */

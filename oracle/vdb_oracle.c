@@ -258,6 +258,18 @@ int vdb_reserve(vdb_t* h, int64_t n_rows) {
   h->cap = n_rows;
   return VDB_OK;
 }
+/* the twin's sharded handle is the plain store: re-partitioning moves nothing, and there are no workspaces to warm */
+int vdb_rebalance(vdb_t* h, int64_t total_rows) {
+  if (!h) return VDB_ERR_ARG;
+  if (total_rows < 0) return fail(h, VDB_ERR_ARG, "rebalance: total_rows must be >= 0");
+  return vdb_reserve(h, total_rows > h->n ? total_rows : h->n);
+}
+int vdb_warm(vdb_t* h, int max_batch, int k, int kp) {
+  (void)k; (void)kp;
+  if (!h) return VDB_ERR_ARG;
+  if (max_batch < 1 || max_batch > (1 << 20)) return fail(h, VDB_ERR_ARG, "warm: max_batch must be in [1, 1048576]");
+  return VDB_OK;
+}
 int vdb_set_row_offset(vdb_t* h, int64_t off) {
   if (!h) return VDB_ERR_ARG;
   h->row_offset = off;
@@ -555,7 +567,7 @@ int vdb_get_stat(vdb_t* h, const char* name, int64_t* value) {
   if (!strcmp(name, "rows")) { *value = h->n; return VDB_OK; }
   if (!strcmp(name, "capacity_rows")) { *value = h->cap; return VDB_OK; }
   if (!strcmp(name, "n_shards")) { *value = h->n_shards ? h->n_shards : 1; return VDB_OK; }
-  if (!strcmp(name, "last_path") || !strcmp(name, "scratch_bytes") || !strcmp(name, "p2p_direct_shards")) { *value = 0; return VDB_OK; }
+  if (!strcmp(name, "last_path") || !strcmp(name, "scratch_bytes") || !strcmp(name, "p2p_direct_shards") || !strcmp(name, "workspace_allocs") || !strcmp(name, "last_fused")) { *value = 0; return VDB_OK; }
   if (!strcmp(name, "last_corpus_passes")) { *value = 1; return VDB_OK; }
   if (!strcmp(name, "mfma_last_overflow") || !strcmp(name, "mfma_last_hits") || !strcmp(name, "mfma_last_skipped_tiles")) { *value = 0; return VDB_OK; }
   return fail(h, VDB_ERR_ARG, "get_stat: unknown stat");

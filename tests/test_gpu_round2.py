@@ -245,12 +245,15 @@ def test_sharded_host_rows_k_larger_than_a_shard_and_device_entry(hip_lib, oracl
     r_idx, r_dist, r_sc = oracle_mod.exact_topk(all_n, q2, 5)
     check_topk(idx, dist, r_idx, r_dist, r_sc, all_n, _qn(oracle_mod, q2), what="sharded overflow rows")
     assert idx[0, 0] == n + 3 and idx[1, 0] == n + 77
-    # what a sharded handle does not serve says so
+    # what a sharded handle does not serve says so (round 3: masks, self-join and device appends are served: test_gpu_round3.py)
     with pytest.raises(VdbError) as e:
-        sh.selfjoin(3)
+        sh.set_row_offset(5)
     assert e.value.code == -5
+    import torch
+    t = torch.zeros((1, dim), device="cuda")
+    o_i = torch.zeros((1, 3), dtype=torch.int64, device="cuda"); o_d = torch.zeros((1, 3), device="cuda")
     with pytest.raises(VdbError):
-        sh.search_masked(queries, 3, np.ones(sh.count(), bool))
+        sh.search_device_noalloc(t.data_ptr(), 1, 3, 0, o_i.data_ptr(), o_d.data_ptr())
     sh.close()
 
 

@@ -143,3 +143,200 @@ def test_fused_search_on_device_pointers_and_a_sharded_handle(hip_lib, oracle_mo
         assert np.array_equal(hi, res[0][0]) and np.array_equal(hd, res[0][1])
     one.close()
     sh.close()
+
+
+# ---- the rest of the ABI on a sharded handle (round 3): where= bitmaps, self-join, device-resident appends,
+# ---- re-partitioning; and the paths a second physical GPU would take, forced on the one GPU of the test box ----
+
+def _pair(dim, dtype, g, n, spec, reserve=None):
+    one = FlatIndex(dim, dtype, True)
+    one.add_synth(0, n, spec)
+    sh = FlatIndex(dim, dtype, True, devices=[0] * g)
+    sh.reserve(n if reserve is None else reserve)
+    sh.add_synth(0, n, spec)
+    return one, sh
+
+
+def _same(a, b, what):
+    assert np.array_equal(a[0], b[0]), f"{what}: ids differ"
+    assert np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)), f"{what}: distances differ in their bits"
+
+
+@pytest.mark.parametrize("g", [2, 3, 8])
+@pytest.mark.parametrize("dtype,kp", [("f32", 0), ("bf16", 40)])
+def test_sharded_handle_serves_masks_device_appends_and_rebalance(hip_lib, oracle_mod, g, dtype, kp):
+    import torch
+    dim, n = 768, 30_011
+    spec = SynthSpec(seed=41, kind=1, n_clusters=173, noise=0.3)
+    qspec = SynthSpec(seed=42, kind=2, noise=0.5, base_kind=1, base_seed=41, base_n=n, base_n_clusters=173, base_noise=0.3)
+    queries = oracle_mod.synth_rows(0, 9, dim, qspec)
+    rows = oracle_mod.normalize_rows(oracle_mod.synth_rows(0, n, dim, spec))
+    one, sh = _pair(dim, dtype, g, n, spec)
+    for remote in (0, 1):                                   # 1: every shard but the first as if on a GPU without peer access
+        sh.set_option("shard_force_remote", remote)
+        for b in (1, 4, 9):
+            _same(sh.search(queries[:b], 10, kp), one.search(queries[:b], 10, kp), f"search g={g} b={b} remote={remote}")
+        # where=: a global bitmap, each shard takes its word-aligned slice (host and device forms)
+        rng = np.random.default_rng(g)
+        for frac in (0.5, 0.01):
+            allow = rng.random(n) < frac
+            got = sh.search_masked(queries[:5], 10, allow, kp)
+            _same(got, one.search_masked(queries[:5], 10, allow, kp), f"masked g={g} {frac} remote={remote}")
+            assert np.all(allow[got[0][got[0] >= 0]])
+            sub = np.flatnonzero(allow)
+            r_idx, r_dist, r_sc = oracle_mod.exact_topk(rows[sub], queries[:5], 10)
+            r_idx = np.where(r_idx >= 0, sub[np.maximum(r_idx, 0)], -1)
+            check_topk(got[0], got[1], r_idx, r_dist, r_sc, rows, _qn(oracle_mod, queries[:5]), what=f"masked g={g} {frac}")
+            bits = np.zeros(((n + 31) // 32) * 4, np.uint8)
+            pk = np.packbits(allow, bitorder="little")
+            bits[: pk.size] = pk
+            d_bits = torch.from_numpy(bits.view(np.int32).copy()).cuda()
+            q_t = torch.from_numpy(queries[:5]).cuda()
+            oi = torch.empty((5, 10), dtype=torch.int64, device="cuda")
+            od = torch.empty((5, 10), dtype=torch.float32, device="cuda")
+            sh.search_masked_device(q_t.data_ptr(), 5, 10, kp, d_bits.data_ptr(), n, oi.data_ptr(), od.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            _same((oi.cpu().numpy(), od.cpu().numpy()), got, f"masked_dev g={g} {frac} remote={remote}")
+    # device-resident appends routed by span (rows on shard 0's device), straddling shard borders and the reserved total
+    extra = np.random.default_rng(9).standard_normal((2_000, dim)).astype(np.float32)
+    t = torch.from_numpy(extra).cuda()
+    torch.cuda.synchronize()
+    one.add_device(t.data_ptr(), 2_000)
+    sh.add_device(t.data_ptr(), 2_000)
+    assert sh.count() == one.count() == n + 2_000
+    q2 = extra[[5, 1_999]]
+    _same(sh.search(q2, 7, kp), one.search(q2, 7, kp), f"after add_dev g={g}")
+    assert sh.search(q2, 1, kp)[0][:, 0].tolist() == [n + 5, n + 1_999]
+    # re-partition: the rows beyond the reserved total sat in the last shard; now the shards are even again
+    per0 = sh.get_stat("rows_per_shard")
+    sh.rebalance(2 * (n + 2_000))
+    assert sh.get_stat("rows_per_shard") > per0 and sh.count() == n + 2_000
+    _same(sh.search(queries, 10, kp), one.search(queries, 10, kp), f"after rebalance g={g}")
+    per1 = sh.get_stat("rows_per_shard")
+    probe = np.array([0, per0 - 1, per0, min(per1, n) - 1, min(per1, n), n, n + 1_999])     # rows either side of the old and new shard borders
+    assert np.array_equal(sh.fetch(probe), one.fetch(probe))
+    sh.add_device(t.data_ptr(), 100)                        # and it keeps growing
+    one.add_device(t.data_ptr(), 100)
+    _same(sh.search(queries[:3], 10, kp), one.search(queries[:3], 10, kp), f"append after rebalance g={g}")
+    sh.rebalance(1000)                                      # a smaller total than what is stored: partitioned for the stored rows
+    _same(sh.search(queries[:3], 10, kp), one.search(queries[:3], 10, kp), f"rebalance down g={g}")
+    one.close(); sh.close()
+
+
+@pytest.mark.parametrize("g", [2, 5])
+def test_sharded_selfjoin_equals_single_store(hip_lib, oracle_mod, g):
+    """vdb_selfjoin on a sharded handle: blocks of rows-as-queries cut at shard borders, every shard scanned, merged —
+    the single store's answer bit for bit (fp32 store and bf16 + rerank), on a sub-range too."""
+    dim, n, k = 768, 23_456, 10
+    spec = SynthSpec(seed=61, kind=1, n_clusters=153, noise=0.3)
+    for dtype, kp in (("f32", 0), ("bf16", 40)):
+        one, sh = _pair(dim, dtype, g, n, spec)
+        for remote in (0, 1):
+            sh.set_option("shard_force_remote", remote)
+            a = sh.selfjoin(k, exclude_self=True, rerank_kprime=kp)
+            b = one.selfjoin(k, exclude_self=True, rerank_kprime=kp)
+            assert not np.any(a[0] == np.arange(n)[:, None])
+            _same(a, b, f"selfjoin g={g} {dtype} remote={remote}")
+        _same(sh.selfjoin(3, exclude_self=False, rerank_kprime=kp, q_row0=4_000, q_n=9_000),
+              one.selfjoin(3, exclude_self=False, rerank_kprime=kp, q_row0=4_000, q_n=9_000), f"selfjoin range g={g} {dtype}")
+        one.close(); sh.close()
+
+
+def test_two_physical_gpus_when_the_box_has_them(hip_lib, oracle_mod, tmp_path):
+    """The cross-device half of vdb_create_sharded (peer copies of the queries, P2P result stores, events across
+    devices) needs a second GPU; the one-GPU box runs the same code through shard_force_remote above."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU on this box")
+    dim, n = 768, 50_000
+    spec = SynthSpec(seed=71, kind=1, n_clusters=223, noise=0.3)
+    qspec = SynthSpec(seed=72, kind=2, noise=0.5, base_kind=1, base_seed=71, base_n=n, base_n_clusters=223, base_noise=0.3)
+    queries = oracle_mod.synth_rows(0, 70, dim, qspec)
+    one = FlatIndex(dim, "bf16", True)
+    one.add_synth(0, n, spec)
+    devs = list(range(torch.cuda.device_count()))
+    sh = FlatIndex(dim, "bf16", True, devices=devs)
+    sh.reserve(n)
+    sh.add_synth(0, n, spec)
+    for b in (1, 4, 33, 70):
+        _same(sh.search(queries[:b], 10, 40), one.search(queries[:b], 10, 40), f"{len(devs)} GPUs b={b}")
+    i1, d1, r1 = sh.search_fetch(queries[:3], 10, 40)
+    i0, d0, r0 = one.search_fetch(queries[:3], 10, 40)
+    assert np.array_equal(i1, i0) and np.array_equal(d1, d0) and np.array_equal(r1, r0)
+    allow = np.arange(n) % 7 == 0
+    _same(sh.search_masked(queries[:4], 10, allow, 40), one.search_masked(queries[:4], 10, allow, 40), "masked, physical GPUs")
+    sh.save(str(tmp_path / "s"))
+    back = FlatIndex.load(str(tmp_path / "s"), "bf16", True, devices=devs[::-1])
+    _same(back.search(queries[:5], 10, 40), one.search(queries[:5], 10, 40), "reload, physical GPUs")
+    for ix in (one, sh, back):
+        ix.close()
+
+
+def test_warm_presizes_every_workspace(hip_lib, oracle_mod):
+    dim, n = 768, 60_000
+    spec = SynthSpec(seed=81, kind=1, n_clusters=244, noise=0.3)
+    queries = oracle_mod.synth_rows(0, 300, dim, SynthSpec(seed=82, kind=0))
+    for devices in (None, [0, 0, 0]):
+        ix = FlatIndex(dim, "bf16", True, devices=devices)
+        ix.reserve(n)
+        ix.add_synth(0, n, spec)
+        ix.warm(300, 10, 40)
+        before = ix.get_stat("workspace_allocs")
+        import torch
+        q_t = torch.from_numpy(queries).cuda()
+        oi = torch.empty((300, 10), dtype=torch.int64, device="cuda")
+        od = torch.empty((300, 10), dtype=torch.float32, device="cuda")
+        for b in (1, 3, 4, 17, 64, 100, 128, 255, 300):
+            ix.search_device(q_t.data_ptr(), b, 10, 40, oi.data_ptr(), od.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert ix.get_stat("workspace_allocs") == before, "a search after vdb_warm grew a workspace"
+        ix.close()
+
+
+def test_collection_on_a_sharded_segment(hip_lib, oracle_mod, tmp_path):
+    """PersistentClient(path, devices=[...]): the reference's calls (add in batches, query with embeddings, where=, get,
+    reopen: src/vectordb.py:149,156-160,215-219,230,259-264) on a row-sharded segment give the single-GPU collection's answers."""
+    from vectordb_amd.chroma_compat import PersistentClient
+    dim, n = 768, 12_345
+    spec = SynthSpec(seed=91, kind=1, n_clusters=111, noise=0.3)
+    raw = oracle_mod.synth_rows(0, n, dim, spec)
+    queries = oracle_mod.synth_rows(0, 6, dim, SynthSpec(seed=92, kind=2, noise=0.4, base_kind=1, base_seed=91, base_n=n, base_n_clusters=111, base_noise=0.3))
+    metas = [{"product_code": str(i), "usda_code": "A" if i % 5 == 0 else "B"} for i in range(n)]
+    ids = [f"item_{i}" for i in range(n)]
+    cols = {}
+    for name, kw in (("one", {}), ("sharded", {"devices": [0, 0, 0, 0]})):
+        client = PersistentClient(path=str(tmp_path / name), dtype="bf16", **kw)
+        col = client.get_or_create_collection(name="actual_products", metadata={"hnsw:space": "cosine"})
+        for lo in range(0, n, 5000):
+            col.add(embeddings=raw[lo:lo + 5000], metadatas=metas[lo:lo + 5000], ids=ids[lo:lo + 5000])
+        cols[name] = (client, col)
+    assert cols["sharded"][1]._index.get_stat("n_shards") == 4 and cols["sharded"][1].count() == n
+
+    def answers(col):
+        out = []
+        for q in range(6):
+            r = col.query(query_embeddings=[queries[q].tolist()], n_results=30, include=["metadatas", "distances", "embeddings"])
+            out.append((r["ids"][0], r["distances"][0], np.asarray(r["embeddings"][0])))
+        r = col.query(query_embeddings=queries[:3], n_results=5, where={"usda_code": "A"}, include=["distances"])
+        out.append((r["ids"], r["distances"]))
+        g = col.get(ids=["item_7", "item_12344", "nope"], include=["embeddings", "metadatas"])
+        out.append((g["ids"], np.asarray(g["embeddings"]), g["metadatas"]))
+        return out
+
+    def plain(x):
+        if isinstance(x, np.ndarray):
+            return x.tolist()
+        if isinstance(x, (list, tuple)):
+            return [plain(y) for y in x]
+        return x
+
+    a, b = answers(cols["one"][1]), answers(cols["sharded"][1])
+    assert plain(a) == plain(b)
+    assert all(i.endswith(("0", "5")) for row in a[6][0] for i in row)
+    cols["sharded"][0].close()                                  # writes vectors.vdb; reopen row-sharded over another shard count
+    again = PersistentClient(path=str(tmp_path / "sharded"), dtype="bf16", devices=[0, 0]).get_collection("actual_products")
+    assert again.count() == n and again._index.get_stat("n_shards") == 2
+    assert plain(answers(again)) == plain(a)
+    again.add(embeddings=raw[:10] * 2.0, ids=[f"more_{i}" for i in range(10)])     # grows past the reopened partition
+    assert again.count() == n + 10 and again.query(query_embeddings=[raw[3].tolist()], n_results=2)["ids"][0] == ["item_3", "more_3"]
+    cols["one"][0].close()

@@ -215,3 +215,36 @@ def test_bench_self_launch_refuses_more_gpus_than_the_node_has():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, timeout=300, env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
     assert p.returncode != 0 and "--gpus 2 but this node shows" in (p.stderr + p.stdout)
+
+
+def test_collection_with_devices_on_the_oracle_twin(oracle_lib, tmp_path):
+    """PersistentClient(path, devices=[...]) (round 3): the Chroma-shaped face on a row-sharded segment — adds that
+    outgrow the partition (vdb_rebalance at every doubling), query with embeddings, where=, get, reopen under another
+    shard count — answers what the single-store collection answers.  (On the twin a sharded handle IS the plain
+    store; what is checked here is the host logic around it.)"""
+    rng = np.random.default_rng(17)
+    rows = rng.standard_normal((700, 16)).astype(np.float32)
+    q = rows[[3, 650]] + 0.01
+    metas = [{"usda_code": "A" if i % 4 == 0 else "B"} for i in range(700)]
+    out = {}
+    for name, kw in (("one", {}), ("sharded", {"devices": [0, 1, 2]})):
+        col = _col(PersistentClient(path=str(tmp_path / name), lib=oracle_lib, **kw))
+        for lo in range(0, 700, 250):
+            col.add(embeddings=rows[lo:lo + 250], metadatas=metas[lo:lo + 250], ids=[f"i{j}" for j in range(lo, min(700, lo + 250))])
+        r = col.query(query_embeddings=q, n_results=5, include=["embeddings", "distances", "metadatas"])
+        w = col.query(query_embeddings=q, n_results=5, where={"usda_code": "A"}, include=["distances"])
+        g = col.get(ids=["i7", "i699"], include=["embeddings"])
+        out[name] = (r["ids"], r["distances"], [np.asarray(e).tolist() for e in r["embeddings"]], w["ids"], w["distances"], np.asarray(g["embeddings"]).tolist())
+        if kw:
+            assert col._index.get_stat("n_shards") == 3 and col._partition_rows >= 700
+            col.persist()
+    assert out["one"] == out["sharded"]
+    again = PersistentClient(path=str(tmp_path / "sharded"), lib=oracle_lib, devices=[0, 1]).get_collection("c")
+    assert again.count() == 700 and again._index.get_stat("n_shards") == 2
+    assert again.query(query_embeddings=q, n_results=5, include=["distances"])["ids"] == out["one"][0]
+    again.add(embeddings=rows[:3] * 3.0, ids=["x0", "x1", "x2"])
+    assert again.count() == 703 and again._partition_rows >= 703
+    ix = again._index
+    ix.warm(8, 5)
+    ix.rebalance(10)
+    assert ix.count() == 703

@@ -114,3 +114,20 @@ def write_xlsx(path, header, rows, sheet_name="Sheet1", inline_from_col=None):
         z.writestr("xl/_rels/workbook.xml.rels", rels)
         z.writestr("xl/sharedStrings.xml", sst)
         z.writestr("xl/worksheets/sheet1.xml", sheet)
+
+
+def record_gate(name: str, text: str) -> None:
+    """Print a full-size gate's figures AND leave them behind in files (pytest -q hides prints): appended to
+    profiles/gates_last_run.txt and, where a gpurun scratch directory exists, to gpurun_out/gates_last_run.txt."""
+    import os
+    import time
+    line = f"[{time.strftime('%Y-%m-%d %H:%M:%S')}] {name}: {text}"
+    print("\n" + line)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for d in ("profiles", "gpurun_out"):
+        try:
+            if os.path.isdir(os.path.join(root, d)):
+                with open(os.path.join(root, d, "gates_last_run.txt"), "a") as fh:
+                    fh.write(line + "\n")
+        except OSError:
+            pass

@@ -27,7 +27,7 @@ SYMBOLS = (
     "vdb_search_scan_dev", "vdb_search_finish_dev",
     "vdb_merge_topk_dev",
     "vdb_selfjoin", "vdb_fetch", "vdb_save", "vdb_load", "vdb_last_timing", "vdb_timing_stats", "vdb_set_option", "vdb_get_stat",
-    "vdb_synth_rows_dev", "vdb_add_synth",
+    "vdb_synth_rows_dev", "vdb_add_synth", "vdb_rebalance", "vdb_warm",
 )
 
 
@@ -61,6 +61,8 @@ def _declare(lib: C.CDLL) -> C.CDLL:
     lib.vdb_last_error.argtypes = [vp]
     lib.vdb_last_error.restype = C.c_char_p
     lib.vdb_reserve.argtypes = [vp, i64]
+    lib.vdb_rebalance.argtypes = [vp, i64]
+    lib.vdb_warm.argtypes = [vp, i32, i32, i32]
     lib.vdb_set_row_offset.argtypes = [vp, i64]
     lib.vdb_add.argtypes = [vp, pf, i64]
     lib.vdb_add_dev.argtypes = [vp, pf, i64]

@@ -16,9 +16,12 @@ Reproduces exactly the slice of the chromadb API the reference touches
 
 The vector segment (chromadb's HNSW index) is a FlatIndex on the GPU; ids and
 metadatas stay on the host, the role sqlite plays inside chromadb.  Embeddings
-are returned from the store itself (vdb_fetch: the L2-normalised fp32 row, which
-is also what chromadb's cosine-space segment hands back) — no second copy is
-kept in host memory.  Search is exact, so results equal Chroma's only up to
+are returned from the store itself (vdb_fetch): the L2-NORMALISED row (bf16-rounded
+on a bf16 store without the fp32 copy), not the embedding as it was added — no second
+copy is kept in host memory.  Whether chromadb hands back normalised rows depends on
+its version (parity unpinned: chromadb is not importable here); the reference uses
+the returned embeddings only inside cosine formulas (src/vectordb.py:288-292,
+analysis/bidirectional_similarity.py:170-173), which do not depend on their scale.  Search is exact, so results equal Chroma's only up to
 HNSW's approximation error.
 
 Persistence is incremental (the reference adds 14 777 rows in three batches,
@@ -85,7 +88,11 @@ class Collection:
 
     def __init__(self, name: str, path: Optional[str], embedding_function=None, metadata: Optional[dict] = None,
                  *, dtype: str = "f32", device: int = 0, rerank_kprime: Optional[int] = None, lib=None,
-                 embeddings_as: str = "numpy", auto_persist: bool = True, fp32_copy: bool = True):
+                 embeddings_as: str = "numpy", auto_persist: bool = True, fp32_copy: bool = True,
+                 devices: Optional[Sequence[int]] = None, expected_rows: Optional[int] = None):
+        """devices=[d0, d1, ...]: the vector segment is ONE store row-sharded over those GPUs inside this process
+        (vdb_create_sharded) — same calls, same answers; the partition follows the collection as it grows
+        (vdb_rebalance at every doubling; expected_rows sizes it up front)."""
         metadata = dict(metadata or {})
         space = metadata.get("hnsw:space", "l2")
         if space != "cosine":
@@ -95,7 +102,10 @@ class Collection:
         self._path = path
         self._embedding_function = embedding_function
         self._dtype = dtype
-        self._device = device
+        self._devices = [int(d) for d in devices] if devices else None
+        self._device = self._devices[0] if self._devices else device
+        self._expected_rows = int(expected_rows or 0)
+        self._partition_rows = 0                  # rows the sharded handle's partition was last made for
         self._lib = lib
         self._rerank_kprime = rerank_kprime
         self._fp32_copy = bool(fp32_copy) or dtype != "bf16"      # bf16 only: 2 instead of 6 bytes per element; the rerank and
@@ -114,10 +124,18 @@ class Collection:
     def _ensure_index(self, dim: int) -> FlatIndex:
         if self._index is None:
             self._dim = dim
-            self._index = FlatIndex(dim, self._dtype, self._fp32_copy, self._device, lib=self._lib)
+            self._index = FlatIndex(dim, self._dtype, self._fp32_copy, self._device, lib=self._lib, devices=self._devices)
         elif dim != self._dim:
             raise ValueError(f"Embedding dimension {dim} does not match collection dimensionality {self._dim}")
         return self._index
+
+    def _ensure_partition(self, total: int) -> None:
+        """Sharded segment: keep the row partition ahead of the collection's size (amortised doubling; the rows move
+        between the GPUs as they are, so answers do not change)."""
+        if self._devices and self._index is not None and total > self._partition_rows:
+            want = max(2 * total if self._partition_rows else total, self._expected_rows, 256 * len(self._devices))
+            self._index.rebalance(want)
+            self._partition_rows = want
 
     def _stored_rows(self, rows) -> np.ndarray:
         """The stored (L2-normalised, fp32) embeddings of the given row indices, from the engine."""
@@ -188,6 +206,7 @@ class Collection:
             if dev_emb is not None:
                 dev_emb = dev_emb[keep].contiguous()
         index = self._ensure_index(emb.shape[1])
+        self._ensure_partition(len(self._ids) + emb.shape[0])
         if dev_emb is not None and dev_emb.device.index == index.device:
             import torch
             torch.cuda.current_stream(dev_emb.device).synchronize()     # the engine ingests on its own stream
@@ -408,10 +427,15 @@ class Collection:
                 head = f.read(32)
             if len(head) == 32 and int(np.frombuffer(head[16:24], dtype=np.int64)[0]) == count:
                 try:
-                    self._index = FlatIndex.load(d, self._dtype, self._fp32_copy, self._device, lib=self._lib)
+                    self._index = FlatIndex.load(d, self._dtype, self._fp32_copy, self._device, lib=self._lib, devices=self._devices)
                     self._vdb_rows = count
+                    self._partition_rows = count          # vdb_load_sharded partitions for the file's row count
                     return
-                except VdbError:      # e.g. a cache written without the fp32 copy, reopened with one: rebuild below
+                except VdbError as exc:
+                    # a cache this configuration cannot use (written without the fp32 copy and reopened with one:
+                    # VDB_ERR_STATE) or a damaged one (VDB_ERR_IO): rebuild below.  Device and memory errors are the caller's.
+                    if exc.code not in (-5, -4):
+                        raise
                     self._index = None
         # no (or a stale) store file: rebuild the index from the embeddings as they were added
         emb_path, npy_path = os.path.join(d, "embeddings.f32"), os.path.join(d, "embeddings.npy")
@@ -423,7 +447,10 @@ class Collection:
         else:
             raise RuntimeError(f"corrupt collection {self.name}: {count} records but no embeddings on disk")
         index = self._ensure_index(self._dim)
-        index.reserve(count)
+        if self._devices:
+            self._ensure_partition(count)
+        else:
+            index.reserve(count)
         for lo in range(0, count, 65536):
             index.add(np.ascontiguousarray(raw[lo:lo + 65536]))
         if index.count() != count:
@@ -452,11 +479,13 @@ class PersistentClient:
 
     def __init__(self, path: str = "./chroma", *, dtype: str = "f32", device: int = 0,
                  rerank_kprime: Optional[int] = None, lib=None, embeddings_as: str = "numpy",
-                 auto_persist: bool = True, fp32_copy: bool = True):
+                 auto_persist: bool = True, fp32_copy: bool = True, devices: Optional[Sequence[int]] = None,
+                 expected_rows: Optional[int] = None):
         self._path = str(path)
         os.makedirs(self._path, exist_ok=True)
         self._opts = dict(dtype=dtype, device=device, rerank_kprime=rerank_kprime, lib=lib,
-                          embeddings_as=embeddings_as, auto_persist=auto_persist, fp32_copy=fp32_copy)
+                          embeddings_as=embeddings_as, auto_persist=auto_persist, fp32_copy=fp32_copy,
+                          devices=list(devices) if devices else None, expected_rows=expected_rows)
         self._open: Dict[str, Collection] = {}
 
     def _exists(self, name: str) -> bool:
@@ -523,7 +552,8 @@ class EphemeralClient(PersistentClient):
         self._path = None
         self._opts = dict(dtype=kw.get("dtype", "f32"), device=kw.get("device", 0),
                           rerank_kprime=kw.get("rerank_kprime"), lib=kw.get("lib"),
-                          embeddings_as=kw.get("embeddings_as", "numpy"), auto_persist=False, fp32_copy=kw.get("fp32_copy", True))
+                          embeddings_as=kw.get("embeddings_as", "numpy"), auto_persist=False, fp32_copy=kw.get("fp32_copy", True),
+                          devices=list(kw["devices"]) if kw.get("devices") else None, expected_rows=kw.get("expected_rows"))
         self._open = {}
 
     def _exists(self, name: str) -> bool:

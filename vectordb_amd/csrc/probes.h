@@ -31,6 +31,26 @@ __global__ __launch_bounds__(256) void probe_read_kernel(const v4u_t* __restrict
   if (acc == 0x9E3779B9u) *sink = acc;   // keeps the loads alive; practically never true
 }
 
+// The same bare read in the FUSED scan's launch shape (scan_fused.h): block b's waves take tiles t_begin + wid, + nwv, ...
+// of the range its block group was dealt — the partition the scan's self-tuned per-XCD shares give, computed on the
+// host from the same share table — so that the figure stays a ceiling for a scan that balances its XCDs.
+struct ProbeRange { long long t_begin, t_end, wid0, nwv; };
+template <int U>
+__global__ __launch_bounds__(256) void probe_read_ranges_kernel(const v4u_t* __restrict__ p, const ProbeRange* __restrict__ rg, unsigned* __restrict__ sink) {
+  const size_t lane = threadIdx.x & 63;
+  const ProbeRange r = rg[blockIdx.x];
+  unsigned acc = 0;
+  for (long long t = r.t_begin + r.wid0 + (threadIdx.x >> 6); t < r.t_end; t += r.nwv) {
+    const v4u_t* q = p + (size_t)t * (U * 64) + lane;
+    v4u_t v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(q + u * 64);
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc ^= v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+  }
+  if (acc == 0x9E3779B9u) *sink = acc;
+}
+
 // Operands of the MFMA probes: RANDOM values (a unit vector's elements are ~ +-0.036), two sets used in turn, so
 // that the multiplier inputs toggle as they do on real rows — on constant or zero operands the chip holds a higher
 // clock and the probe overstates what a real kernel can reach.

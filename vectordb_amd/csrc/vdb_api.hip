@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -73,6 +74,8 @@ struct vdb {
   double last_bytes = 0.0;
   int last_path = 0;              // kernel family of the last search: 0 = GEMV scan, 4/5/6 = MFMA pass kernels (launch.h)
   int last_passes = 0;            // corpus passes of the last search (GEMV: launches; MFMA: 1)
+  int last_fused = 0;             // the last search ran as one-launch fused scans (scan_fused.h)
+  int64_t n_ws_allocs = 0;        // workspace (re)allocations so far (stat "workspace_allocs": vdb_warm's effect can be checked)
   int n_cu = 256;
   // options
   int scan_blocks_per_cu = 2;    // 2 x 256 threads per CU: 96 KiB in flight per CU; 4 measured 3-4 % slower at every shard size (bf16)
@@ -113,9 +116,14 @@ struct vdb {
   std::vector<vdb*> shards;
   std::vector<hipEvent_t> shard_done;   // per shard: its result is in the gather buffer
   std::vector<char> shard_direct;       // per shard: its finish kernel stores straight into shard 0's memory (same device or P2P)
+  int shard_force_remote = 0;           // test hook: every shard but the first takes the no-peer-access path (query and result peer copies)
+  int shard_serial_streams = 0;         // diagnostic: shard 0 on its own stream like the others (the round-2 form)
   hipEvent_t ev_q = nullptr;            // the queries are ready on the caller's stream
   int64_t per = 0;                      // rows per shard (multiple of 256); 0 = not reserved yet
   DevBuf w_gather;                      // on shard 0's device: [g][b][k] idx (int64) then [g][b][k] dist (fp32)
+  int64_t issue_ns_sum = 0, issue_calls = 0;   // host time spent inside sharded searches (stat "sharded_issue_ns_avg" reads and resets)
+  int64_t issue_phase_ns[8] = {};              // diagnostic (stat "sharded_issue_phase_<i>"): 0 prologue + ev_q record, 1 set-device + ev_q waits,
+                                               // 2 query copy + prep, 3 search_core (launches), 4 result copies + shard_done records, 5 main waits, 6 merge launch
   std::string err;
 };
 
@@ -145,6 +153,7 @@ int ensure(vdb_t* h, DevBuf& b, size_t bytes) {
   size_t want = std::max(bytes, (size_t)4096);
   HIP_TRY(h, hipMalloc(&b.p, want));
   b.bytes = want;
+  h->n_ws_allocs++;
   return VDB_OK;
 }
 
@@ -492,6 +501,7 @@ int search_core(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
   h->last_bytes = 0.0;
   h->last_path = 0;
   h->last_passes = 0;
+  h->last_fused = 0;
 
   if (n_rows == 0) {
     // empty store: all -1 / +inf
@@ -520,6 +530,7 @@ int search_core(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
   if (fuses(h, b, kk)) {
     if ((rc = ensure_parts(h, W, (size_t)std::min(b, 4) * grid * round_up(kk, 4)))) return rc;
     if ((rc = gemv_fused(h, ptrs_of(W), (unsigned*)h->w_ticket.p, qn, q_raw, b, kk, k, kp, self_row0, allow, grid, out_idx, out_dist, st))) return rc;
+    h->last_fused = 1;
     if (h->ev_on) { HIP_TRY(h, hipEventRecord(h->ev[1], st)); HIP_TRY(h, hipEventRecord(h->ev[2], st)); h->timing_valid = true; }
     return VDB_OK;
   }
@@ -723,6 +734,64 @@ int vdb_reserve(vdb_t* h, int64_t n_rows) {
   return grow(h, n_rows);
 }
 
+// Re-partition a sharded handle for total_rows rows: the stored rows move between the shards' GPUs as they are (device
+// to device, verbatim bits), so that a store that outgrew the partition vdb_reserve fixed — its last shard takes
+// every row beyond it — is balanced again.  Searches return what they returned before.
+int vdb_rebalance(vdb_t* h, int64_t total_rows) {
+  if (!h) return VDB_ERR_ARG;
+  if (total_rows < 0) return fail(h, VDB_ERR_ARG, "rebalance: total_rows must be >= 0");
+  if (!is_sharded(h)) return vdb_reserve(h, std::max(total_rows, h->n));   // one shard: capacity is all there is to fix
+  const int64_t g = (int64_t)h->shards.size();
+  const int64_t total = std::max(total_rows, h->n);
+  if (total > g * (int64_t)0x7fffff00) return fail(h, VDB_ERR_ARG, "rebalance: total_rows out of range");
+  const int64_t per = std::max<int64_t>(256, ((total + g - 1) / g + 255) / 256 * 256);
+  if (h->n == 0) h->per = 0;                                 // nothing stored: a fresh partition
+  if (h->n == 0 || per == h->per) return vdb_reserve(h, total);
+  for (vdb_t* c : h->shards)
+    if (c->split[0].pending || c->split[1].pending) return fail(h, VDB_ERR_STATE, "rebalance: a two-phase scan is pending");
+  int rc;
+  for (vdb_t* c : h->shards) { if ((rc = set_device(c))) return fail(h, rc, c->err); HIP_TRY(h, hipDeviceSynchronize()); }
+  const int64_t old_per = h->per;
+  struct NewRows { float* f32 = nullptr; uint16_t* b16 = nullptr; int64_t n = 0, cap = 0; };
+  std::vector<NewRows> nr((size_t)g);
+  auto drop = [&]() { for (int64_t s = 0; s < g; ++s) { (void)hipSetDevice(h->shards[(size_t)s]->device); if (nr[(size_t)s].f32) (void)hipFree(nr[(size_t)s].f32); if (nr[(size_t)s].b16) (void)hipFree(nr[(size_t)s].b16); } };
+  const size_t ld = (size_t)h->ld;
+  for (int64_t s = 0; s < g; ++s) {
+    vdb_t* c = h->shards[(size_t)s];
+    const int64_t lo = s * per, hi = s == g - 1 ? std::max(h->n, lo) : std::min(h->n, (s + 1) * per);
+    NewRows& w = nr[(size_t)s];
+    w.n = std::max<int64_t>(0, hi - lo);
+    w.cap = (std::max(per, w.n) + 255) / 256 * 256;
+    if (set_device(c) != VDB_OK) { drop(); return fail(h, VDB_ERR_DEVICE, c->err); }
+    hipError_t e = hipSuccess;
+    if (c->keep_f32) e = hipMalloc((void**)&w.f32, sizeof(float) * ld * (size_t)w.cap);
+    if (e == hipSuccess && c->dtype == VDB_BF16) {
+      e = hipMalloc((void**)&w.b16, sizeof(uint16_t) * ld * (size_t)w.cap);
+      if (e == hipSuccess) e = hipMemset(w.b16, 0, sizeof(uint16_t) * ld * (size_t)w.cap);   // rows beyond n are read (and masked) by the tiled kernels
+    }
+    // the old shards whose rows [o * old_per, o * old_per + n_o) overlap [lo, lo + w.n)
+    for (int64_t o = 0; e == hipSuccess && o < g && w.n > 0; ++o) {
+      vdb_t* src = h->shards[(size_t)o];
+      const int64_t olo = o * old_per, a = std::max(lo, olo), b = std::min(lo + w.n, olo + src->n);
+      if (b <= a) continue;
+      if (w.f32) e = hipMemcpyPeer(w.f32 + (size_t)(a - lo) * ld, c->device, src->rows_f32 + (size_t)(a - olo) * ld, src->device, sizeof(float) * ld * (size_t)(b - a));
+      if (e == hipSuccess && w.b16) e = hipMemcpyPeer(w.b16 + (size_t)(a - lo) * ld, c->device, src->rows_bf16 + (size_t)(a - olo) * ld, src->device, sizeof(uint16_t) * ld * (size_t)(b - a));
+    }
+    if (e != hipSuccess) { drop(); return fail(h, e == hipErrorOutOfMemory ? VDB_ERR_MEMORY : VDB_ERR_DEVICE, std::string("rebalance: ") + hipGetErrorString(e)); }
+  }
+  for (int64_t s = 0; s < g; ++s) {
+    vdb_t* c = h->shards[(size_t)s];
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    if (c->rows_f32) (void)hipFree(c->rows_f32);
+    if (c->rows_bf16) (void)hipFree(c->rows_bf16);
+    c->rows_f32 = nr[(size_t)s].f32; c->rows_bf16 = nr[(size_t)s].b16;
+    c->n = nr[(size_t)s].n; c->cap = nr[(size_t)s].cap; c->row_offset = s * per;
+  }
+  h->per = per;
+  return set_device(h);
+}
+
 namespace {
 // The shard that owns global row r of a sharded handle, and the rows [r, r+len) of an append that land in it.
 struct ShardSpan { int s; int64_t count; };
@@ -776,7 +845,29 @@ int vdb_add_dev(vdb_t* h, const float* rows_dev, int64_t n) {
   if (!h) return VDB_ERR_ARG;
   if (n < 0 || (n > 0 && !rows_dev)) return fail(h, VDB_ERR_ARG, "vdb_add_dev: bad rows/n");
   if (n == 0) return VDB_OK;
-  NOT_ON_SHARDED(h, "vdb_add_dev");
+  if (is_sharded(h)) {   // the rows live on shard 0's device: each span goes to its shard in place, or over a peer copy
+    if (!h->per) return fail(h, VDB_ERR_STATE, "vdb_add_dev: call vdb_reserve(total rows) on a sharded handle first (it fixes the row partition)");
+    const int64_t chunk = std::max<int64_t>(1, (int64_t)(64u << 20) / ((int64_t)h->dim * 4));
+    for (int64_t r = 0; r < n;) {
+      const ShardSpan sp = shard_span(h, h->n, n - r);
+      vdb_t* c = h->shards[(size_t)sp.s];
+      const float* src = rows_dev + (size_t)r * h->dim;
+      int rc;
+      if (c->device == h->device && !(h->shard_force_remote && sp.s > 0)) {
+        if ((rc = vdb_add_dev(c, src, sp.count))) return fail(h, rc, c->err);
+      } else {
+        if ((rc = set_device(c))) return fail(h, rc, c->err);
+        if ((rc = ensure(c, c->w_stage, (size_t)std::min(sp.count, chunk) * h->dim * 4))) return fail(h, rc, c->err);
+        for (int64_t o = 0; o < sp.count; o += chunk) {
+          const int64_t m = std::min(chunk, sp.count - o);
+          HIP_TRY(h, hipMemcpyPeer(c->w_stage.p, c->device, src + (size_t)o * h->dim, h->device, (size_t)m * h->dim * 4));
+          if ((rc = vdb_add_dev(c, (const float*)c->w_stage.p, m))) return fail(h, rc, c->err);
+        }
+      }
+      r += sp.count; h->n += sp.count;
+    }
+    return VDB_OK;
+  }
   int rc = set_device(h);
   if (rc) return rc;
   if ((rc = reserve_for_add(h, n))) return rc;
@@ -793,51 +884,103 @@ int vdb_count(vdb_t* h, int64_t* n) {
 }
 
 namespace {
+// What a sharded search may carry beside the plain arguments.
+struct ShardedExtra {
+  const uint32_t* allow_host = nullptr;   // where= bitmap over GLOBAL rows, in host memory ...
+  const uint32_t* allow_dev0 = nullptr;   // ... or on shard 0's device (one of the two, or neither)
+  int64_t self_global0 = -1;              // >= 0: query q must not return global row self_global0 + q (self-join; the block lies in ONE shard)
+  bool q_unit_ld = false;                 // the queries are unit vectors laid out [b][ld] (stored rows): used as they are
+};
+
 // Search on a sharded handle: queries and outputs live on shard 0's device, `st` is a stream of that device.
 // Every shard scans its rows on its own stream (all devices run together), its finish kernel stores the k results
 // straight into shard 0's gather buffer (same device, or over xGMI with peer access; a peer copy otherwise), and one
-// merge kernel on `st` ranks the g lists.  One host thread, no host synchronisation.
-int sharded_search_dev(vdb_t* h, const float* q_dev0, int b, int k, int kp, int64_t* out_idx, float* out_dist, hipStream_t st) {
+// merge kernel on `st` ranks the g lists.  One host thread, no host synchronisation.  Shard 0 (it lives on the
+// caller's device) runs on the CALLER's stream: no cross-stream wait before it and none behind it — a
+// hipStreamWaitEvent on a pending event costs the host ~5 us (profiles/r03_sharded_issue_cost.json), and two per
+// shard were 60 % of the call.
+int sharded_search_dev(vdb_t* h, const float* q_dev0, int b, int k, int kp, int64_t* out_idx, float* out_dist, hipStream_t st,
+                       const ShardedExtra& x = ShardedExtra()) {
   const int g = (int)h->shards.size();
   int rc;
+  struct IssueClock {   // host time of the whole call, whatever way it returns
+    vdb_t* h; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    ~IssueClock() { h->issue_ns_sum += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); h->issue_calls++; }
+  } issue_clock{h};
   if ((rc = set_device(h))) return rc;
   const size_t bk = (size_t)b * k;
   if ((rc = ensure(h, h->w_gather, (size_t)g * bk * 12))) return rc;
   int64_t* g_idx = (int64_t*)h->w_gather.p;
   float* g_dist = (float*)((char*)h->w_gather.p + (size_t)g * bk * 8);
+  auto lap = [&](int ph, std::chrono::steady_clock::time_point& t) {
+    const auto t1 = std::chrono::steady_clock::now();
+    h->issue_phase_ns[ph] += std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t).count();
+    t = t1;
+  };
+  auto tp = issue_clock.t0;
+  const bool masked = x.allow_host || x.allow_dev0;
+  const size_t q_bytes = (size_t)b * (x.q_unit_ld ? h->ld : h->dim) * 4;
   HIP_TRY(h, hipEventRecord(h->ev_q, st));   // the queries are ready; the previous call's merge (earlier on st) has read the gather buffer
+  lap(0, tp);
   for (int s = 0; s < g; ++s) {
     vdb_t* c = h->shards[(size_t)s];
+    // shard 0 on the caller's stream (stream order does what the two events do for the others); the test hook
+    // shard_force_remote treats every other shard as if it lived on another GPU without peer access
+    const bool inline0 = s == 0 && !h->shard_serial_streams;
+    const bool remote = c->device != h->device || (h->shard_force_remote && s > 0);
+    hipStream_t cs = inline0 ? st : c->stream;
     if ((rc = set_device(c))) return fail(h, rc, c->err);
-    HIP_TRY(h, hipStreamWaitEvent(c->stream, h->ev_q, 0));
+    if (!inline0) HIP_TRY(h, hipStreamWaitEvent(cs, h->ev_q, 0));
+    lap(1, tp);
     const float* q_local = q_dev0;
-    if (c->device != h->device) {
-      if ((rc = ensure(c, c->w_stage, (size_t)b * h->dim * 4))) return fail(h, rc, c->err);
-      HIP_TRY(h, hipMemcpyPeerAsync(c->w_stage.p, c->device, q_dev0, h->device, (size_t)b * h->dim * 4, c->stream));
+    if (remote) {
+      if ((rc = ensure(c, c->w_stage, q_bytes))) return fail(h, rc, c->err);
+      HIP_TRY(h, hipMemcpyPeerAsync(c->w_stage.p, c->device, q_dev0, h->device, q_bytes, cs));
       q_local = (const float*)c->w_stage.p;
     }
-    const float* qn = nullptr;
+    // this shard's slice of the eligibility bitmap: its first global row is a multiple of 256, so the slice starts on a word
+    const unsigned* allow = nullptr;
+    if (masked && c->n > 0) {
+      const size_t word0 = (size_t)(c->row_offset >> 5), words = (size_t)((c->n + 31) / 32);
+      if (x.allow_dev0 && !remote) {
+        allow = x.allow_dev0 + word0;
+      } else {
+        if ((rc = ensure(c, c->w_mask, words * 4))) return fail(h, rc, c->err);
+        if (x.allow_host) HIP_TRY(h, hipMemcpyAsync(c->w_mask.p, x.allow_host + word0, words * 4, hipMemcpyHostToDevice, cs));
+        else HIP_TRY(h, hipMemcpyPeerAsync(c->w_mask.p, c->device, x.allow_dev0 + word0, h->device, words * 4, cs));
+        allow = (const unsigned*)c->w_mask.p;
+      }
+    }
+    const float* qn = q_local;
     bool raw = false;
-    if ((rc = prep_or_pass(c, q_local, b, k, kp, false, c->stream, &qn, &raw))) return fail(h, rc, c->err);
+    if (!x.q_unit_ld && (rc = prep_or_pass(c, q_local, b, k, kp, masked, cs, &qn, &raw))) return fail(h, rc, c->err);
+    int64_t self0 = -1;
+    if (x.self_global0 >= 0 && x.self_global0 >= c->row_offset && x.self_global0 < c->row_offset + c->n) self0 = x.self_global0 - c->row_offset;
     int64_t* oi = g_idx + (size_t)s * bk;
     float* od = g_dist + (size_t)s * bk;
-    if (!h->shard_direct[(size_t)s]) {
+    const bool direct = h->shard_direct[(size_t)s] && !(h->shard_force_remote && s > 0);
+    if (!direct) {
       if ((rc = ensure(c, c->w_out_i, bk * 12))) return fail(h, rc, c->err);
       oi = (int64_t*)c->w_out_i.p;
       od = (float*)((char*)c->w_out_i.p + bk * 8);
     }
-    if ((rc = search_core(c, qn, b, k, kp, -1, oi, od, c->stream, nullptr, raw))) return fail(h, rc, c->err);
-    if (!h->shard_direct[(size_t)s]) {
-      HIP_TRY(h, hipMemcpyPeerAsync(g_idx + (size_t)s * bk, h->device, oi, c->device, bk * 8, c->stream));
-      HIP_TRY(h, hipMemcpyPeerAsync(g_dist + (size_t)s * bk, h->device, od, c->device, bk * 4, c->stream));
+    lap(2, tp);
+    if ((rc = search_core(c, qn, b, k, kp, self0, oi, od, cs, allow, raw))) return fail(h, rc, c->err);
+    lap(3, tp);
+    if (!direct) {
+      HIP_TRY(h, hipMemcpyPeerAsync(g_idx + (size_t)s * bk, h->device, oi, c->device, bk * 8, cs));
+      HIP_TRY(h, hipMemcpyPeerAsync(g_dist + (size_t)s * bk, h->device, od, c->device, bk * 4, cs));
     }
-    HIP_TRY(h, hipEventRecord(h->shard_done[(size_t)s], c->stream));
+    if (!inline0) HIP_TRY(h, hipEventRecord(h->shard_done[(size_t)s], cs));
+    lap(4, tp);
   }
   if ((rc = set_device(h))) return rc;
-  for (int s = 0; s < g; ++s) HIP_TRY(h, hipStreamWaitEvent(st, h->shard_done[(size_t)s], 0));
+  for (int s = h->shard_serial_streams ? 0 : 1; s < g; ++s) HIP_TRY(h, hipStreamWaitEvent(st, h->shard_done[(size_t)s], 0));
+  lap(5, tp);
   hipLaunchKernelGGL(merge_shards_kernel, dim3(b), dim3(256), 0, st, (const float*)g_dist, (long long)bk, (const long long*)g_idx,
                      (long long)bk, g, k, (long long*)out_idx, out_dist);
   HIP_TRY(h, hipGetLastError());
+  lap(6, tp);
   return VDB_OK;
 }
 }  // namespace
@@ -855,6 +998,45 @@ int vdb_search_dev(vdb_t* h, const float* queries_dev, int b, int k, int kp, int
   bool raw = false;
   if ((rc = prep_or_pass(h, queries_dev, b, k, kp, false, st, &qn, &raw))) return rc;
   return search_core(h, qn, b, k, kp, -1, out_idx_dev, out_dist_dev, st, nullptr, raw);
+}
+
+// Size every workspace a search of up to max_batch queries with these k / k' needs on the store as it is now, so that
+// no later search of that shape grows one (a growth drains the device, frees and allocates): one dummy search per
+// kernel family the batch sizes up to max_batch can take, on zero queries, results discarded.
+int vdb_warm(vdb_t* h, int max_batch, int k, int kp) {
+  if (!h) return VDB_ERR_ARG;
+  if (max_batch < 1 || max_batch > (1 << 20)) return fail(h, VDB_ERR_ARG, "warm: max_batch must be in [1, 1048576]");
+  int rc = set_device(h);
+  if (rc) return rc;
+  float* q = nullptr; int64_t* oi = nullptr; float* od = nullptr;
+  hipError_t e = hipMalloc((void**)&q, (size_t)max_batch * h->dim * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&oi, (size_t)max_batch * k * 8);
+  if (e == hipSuccess) e = hipMalloc((void**)&od, (size_t)max_batch * k * 4);
+  rc = e == hipSuccess ? VDB_OK : fail(h, VDB_ERR_MEMORY, std::string("warm: ") + hipGetErrorString(e));
+  if (rc == VDB_OK) {   // isotropic random queries (all-zero ones would tie every score and overflow the batched path's candidate buffers)
+    vdb_synth_spec sp;
+    memset(&sp, 0, sizeof sp);
+    sp.seed = 0x5eed; sp.kind = 0;
+    const int blocks = (int)std::min<int64_t>(((int64_t)max_batch + 3) / 4, (int64_t)h->n_cu * 8);
+    hipLaunchKernelGGL(synth_rows_kernel, dim3(blocks), dim3(256), 0, h->stream, q, 0LL, (long long)max_batch, h->dim, h->dim, sp);
+    if (hipGetLastError() != hipSuccess) rc = fail(h, VDB_ERR_DEVICE, "warm: query generation failed");
+  }
+  // one batch per family boundary: 1..4 (fused scan), 64 (streaming kernel / chunked scan), 128, 256-multiples, the whole batch
+  const int sizes[] = {1, 4, 5, 64, 65, 128, 129, 512, max_batch};
+  int done_b = 0;
+  for (int b : sizes) {
+    b = std::min(b, max_batch);
+    if (rc != VDB_OK || b <= done_b) continue;
+    rc = vdb_search_dev(h, q, b, k, kp, oi, od, h->stream);
+    done_b = b;
+  }
+  if (hipStreamSynchronize(h->stream) != hipSuccess && rc == VDB_OK) rc = fail(h, VDB_ERR_DEVICE, "warm: the dummy searches failed");
+  if (is_sharded(h)) for (vdb_t* c : h->shards) { (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->stream); }
+  (void)hipSetDevice(h->device);
+  if (q) (void)hipFree(q);
+  if (oi) (void)hipFree(oi);
+  if (od) (void)hipFree(od);
+  return rc;
 }
 
 // vdb_search_dev for callers that cannot allocate (HIP graph capture, tight serving loops): the GEMV scan with
@@ -1042,12 +1224,16 @@ int vdb_search_fetch(vdb_t* h, const float* queries_host, int b, int k, int kp, 
 int vdb_search_masked_dev(vdb_t* h, const float* queries_dev, int b, int k, int kp, const uint32_t* allow_dev,
                           int64_t n_bits, int64_t* out_idx_dev, float* out_dist_dev, void* stream) {
   if (!h) return VDB_ERR_ARG;
-  NOT_ON_SHARDED(h, "vdb_search_masked_dev");
   if (!allow_dev && h->n > 0) return fail(h, VDB_ERR_ARG, "search_masked: NULL bitmap");
   if (n_bits != h->n) return fail(h, VDB_ERR_ARG, "search_masked: the bitmap must hold one bit per stored row");
   int rc = check_search_args(h, queries_dev, b, k, kp, out_idx_dev, out_dist_dev);
   if (rc) return rc;
   if (b == 0) return VDB_OK;
+  if (is_sharded(h)) {   // the bitmap is over GLOBAL rows (on shard 0's device): every shard takes its word-aligned slice
+    ShardedExtra x;
+    x.allow_dev0 = allow_dev;
+    return sharded_search_dev(h, queries_dev, b, k, kp, out_idx_dev, out_dist_dev, (hipStream_t)stream, x);
+  }
   if ((rc = set_device(h))) return rc;
   hipStream_t st = (hipStream_t)stream;
   const float* qn = nullptr;
@@ -1059,13 +1245,26 @@ int vdb_search_masked_dev(vdb_t* h, const float* queries_dev, int b, int k, int 
 int vdb_search_masked(vdb_t* h, const float* queries_host, int b, int k, int kp, const uint32_t* allow_host,
                       int64_t n_bits, int64_t* out_idx, float* out_dist) {
   if (!h) return VDB_ERR_ARG;
-  NOT_ON_SHARDED(h, "vdb_search_masked");
   if (!allow_host && h->n > 0) return fail(h, VDB_ERR_ARG, "search_masked: NULL bitmap");
   if (n_bits != h->n) return fail(h, VDB_ERR_ARG, "search_masked: the bitmap must hold one bit per stored row");
   int rc = check_search_args(h, queries_host, b, k, kp, out_idx, out_dist);
   if (rc) return rc;
   if (b == 0) return VDB_OK;
   if ((rc = set_device(h))) return rc;
+  if (is_sharded(h)) {   // queries to shard 0's device, each shard's slice of the host bitmap straight to its own device
+    const size_t ibytes = (size_t)b * k * 8, dbytes = (size_t)b * k * 4;
+    if ((rc = ensure(h, h->w_stage, (size_t)b * h->dim * 4))) return rc;
+    if ((rc = ensure(h, h->w_out_i, ibytes + dbytes))) return rc;
+    HIP_TRY(h, hipMemcpyAsync(h->w_stage.p, queries_host, (size_t)b * h->dim * 4, hipMemcpyHostToDevice, h->stream));
+    ShardedExtra x;
+    x.allow_host = allow_host;
+    if ((rc = sharded_search_dev(h, (const float*)h->w_stage.p, b, k, kp, (int64_t*)h->w_out_i.p, (float*)((char*)h->w_out_i.p + ibytes), h->stream, x))) return rc;
+    HIP_TRY(h, hipMemcpyAsync(out_idx, h->w_out_i.p, ibytes, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(out_dist, (char*)h->w_out_i.p + ibytes, dbytes, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (vdb_t* c : h->shards) { if ((rc = set_device(c))) return fail(h, rc, c->err); HIP_TRY(h, hipStreamSynchronize(c->stream)); }   // the bitmap copies read the caller's array
+    return VDB_OK;
+  }
   const size_t words = (size_t)((h->n + 31) / 32);
   if ((rc = ensure(h, h->w_mask, std::max<size_t>(words, 1) * 4))) return rc;
   if ((rc = ensure(h, h->w_stage, (size_t)b * h->dim * 4))) return rc;
@@ -1101,15 +1300,93 @@ int vdb_merge_topk_dev(vdb_t* h, const float* cd, int64_t dstride, const int64_t
   return VDB_OK;
 }
 
+namespace {
+// The self-join on a sharded handle (C5 over the GPUs of one process): blocks of at most 4096 rows-as-queries, each
+// block cut at shard borders so that it lies in ONE shard (the owner excludes row q0 + q for query q, the others
+// exclude nothing).  The owner turns its stored rows into the block's fp32 unit queries, they go to shard 0's device,
+// and the block is searched like any batch: every shard scans its rows, P2P stores, one merge.  Results leave through
+// two pinned buffers: the host drains block j - 1 while block j computes.
+int sharded_selfjoin(vdb_t* h, int64_t q_row0, int64_t q_n, int k, int exclude_self, int kp, int64_t* out_idx, float* out_dist) {
+  int rc;
+  const int qblock = kMfMaxQueriesPerCall;
+  const size_t ibytes = (size_t)qblock * k * 8, dbytes = (size_t)qblock * k * 4, obytes = ibytes + dbytes;
+  if ((rc = ensure(h, h->w_q, (size_t)qblock * h->ld * 4))) return rc;
+  if ((rc = ensure(h, h->w_out_i, 2 * obytes))) return rc;
+  if (h->pin_bytes < 2 * obytes) {
+    if (h->pin) { HIP_TRY(h, hipStreamSynchronize(h->stream)); HIP_TRY(h, hipHostFree(h->pin)); h->pin = nullptr; h->pin_bytes = 0; }
+    HIP_TRY(h, hipHostMalloc(&h->pin, 2 * obytes, hipHostMallocDefault));
+    h->pin_bytes = 2 * obytes;
+  }
+  hipEvent_t copied[2] = {nullptr, nullptr}, q_ready = nullptr;
+  auto cleanup = [&]() { for (hipEvent_t e : copied) if (e) (void)hipEventDestroy(e); if (q_ready) (void)hipEventDestroy(q_ready); };
+  if (hipEventCreateWithFlags(&copied[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&copied[1], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&q_ready, hipEventDisableTiming) != hipSuccess) {
+    cleanup();
+    return fail(h, VDB_ERR_DEVICE, "selfjoin: event creation failed");
+  }
+  auto drain = [&](int64_t q0, int cb, int slot) -> int {
+    HIP_TRY(h, hipEventSynchronize(copied[slot]));
+    const char* src = (const char*)h->pin + (size_t)slot * obytes;
+    memcpy(out_idx + (size_t)(q0 - q_row0) * k, src, (size_t)cb * k * 8);
+    memcpy(out_dist + (size_t)(q0 - q_row0) * k, src + ibytes, (size_t)cb * k * 4);
+    return VDB_OK;
+  };
+  int64_t prev_q0 = -1; int prev_cb = 0, prev_slot = 0, slot = 0;
+  rc = VDB_OK;
+  for (int64_t q0 = q_row0; q0 < q_row0 + q_n && rc == VDB_OK; slot ^= 1) {
+    const ShardSpan sp = shard_span(h, q0, std::min<int64_t>(qblock, q_row0 + q_n - q0));
+    const int cb = (int)sp.count;
+    vdb_t* o = h->shards[(size_t)sp.s];
+    int64_t* d_idx = (int64_t*)((char*)h->w_out_i.p + (size_t)slot * obytes);
+    float* d_dist = (float*)((char*)d_idx + ibytes);
+    auto body = [&]() -> int {
+      int r2;
+      // the owner's rows as fp32 unit queries [cb][ld], on the owner's device, then on shard 0's
+      if ((r2 = set_device(o))) return r2;
+      if ((r2 = ensure(o, o->w_q1, (size_t)qblock * h->ld * 4))) return r2;
+      HIP_TRY(h, hipStreamWaitEvent(o->stream, copied[slot ^ 1], 0));   // (no-op before the first record) the previous block's searches have read the query buffer
+      hipLaunchKernelGGL(rows_to_f32_kernel, dim3(std::min(4096, (cb * h->ld + 255) / 256)), dim3(256), 0, o->stream,
+                         o->keep_f32 ? o->rows_f32 : nullptr, o->rows_bf16, h->ld, (long long)(q0 - o->row_offset), cb, (float*)o->w_q1.p);
+      HIP_TRY(h, hipGetLastError());
+      if (o->device != h->device) HIP_TRY(h, hipMemcpyPeerAsync(h->w_q.p, h->device, o->w_q1.p, o->device, (size_t)cb * h->ld * 4, o->stream));
+      else HIP_TRY(h, hipMemcpyAsync(h->w_q.p, o->w_q1.p, (size_t)cb * h->ld * 4, hipMemcpyDeviceToDevice, o->stream));
+      HIP_TRY(h, hipEventRecord(q_ready, o->stream));
+      if ((r2 = set_device(h))) return r2;
+      HIP_TRY(h, hipStreamWaitEvent(h->stream, q_ready, 0));
+      ShardedExtra x;
+      x.q_unit_ld = true;
+      x.self_global0 = exclude_self ? q0 : -1;
+      if ((r2 = sharded_search_dev(h, (const float*)h->w_q.p, cb, k, kp, d_idx, d_dist, h->stream, x))) return r2;
+      char* dst = (char*)h->pin + (size_t)slot * obytes;
+      HIP_TRY(h, hipMemcpyAsync(dst, d_idx, (size_t)cb * k * 8, hipMemcpyDeviceToHost, h->stream));
+      HIP_TRY(h, hipMemcpyAsync(dst + ibytes, d_dist, (size_t)cb * k * 4, hipMemcpyDeviceToHost, h->stream));
+      HIP_TRY(h, hipEventRecord(copied[slot], h->stream));
+      return VDB_OK;
+    };
+    rc = body();
+    if (rc == VDB_OK && prev_q0 >= 0) rc = drain(prev_q0, prev_cb, prev_slot);
+    prev_q0 = q0; prev_cb = cb; prev_slot = slot;
+    q0 += cb;
+  }
+  if (rc == VDB_OK && prev_q0 >= 0) rc = drain(prev_q0, prev_cb, prev_slot);
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  for (vdb_t* c : h->shards) { (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->stream); }
+  (void)hipSetDevice(h->device);
+  cleanup();
+  return rc;
+}
+}  // namespace
+
 int vdb_selfjoin(vdb_t* h, int64_t q_row0, int64_t q_n, int k, int exclude_self, int kp, int64_t* out_idx,
                  float* out_dist) {
   if (!h) return VDB_ERR_ARG;
-  NOT_ON_SHARDED(h, "vdb_selfjoin");
   if (q_row0 < 0 || q_n < 0 || q_row0 + q_n > h->n) return fail(h, VDB_ERR_ARG, "selfjoin: query range outside the store");
   int rc = check_search_args(h, h, q_n > 0 ? 1 : 0, k, kp, out_idx, out_dist);
   if (rc) return rc;
   if (q_n == 0) return VDB_OK;
   if ((rc = set_device(h))) return rc;
+  if (is_sharded(h)) return sharded_selfjoin(h, q_row0, q_n, k, exclude_self, kp, out_idx, out_dist);
   // Blocks of 4096 rows-as-queries.  The device never waits for the host: block j's results go to one of two
   // device buffers, a copy stream brings them to pinned memory while block j+1 computes, and the host moves
   // block j-1 into the caller's arrays meanwhile.
@@ -1426,6 +1703,8 @@ int vdb_timing_stats(vdb_t* h, int64_t* n_searches, double* scan_ms_sum, double*
 
 int vdb_set_option(vdb_t* h, const char* name, int64_t value) {
   if (!h || !name) return VDB_ERR_ARG;
+  if (is_sharded(h) && !strcmp(name, "shard_force_remote")) { h->shard_force_remote = value != 0; return VDB_OK; }
+  if (is_sharded(h) && !strcmp(name, "shard_own_stream_for_shard0")) { h->shard_serial_streams = value != 0; return VDB_OK; }
   if (is_sharded(h)) {   // every shard gets the same setting
     for (vdb_t* c : h->shards) { const int rc = vdb_set_option(c, name, value); if (rc) return fail(h, rc, c->err); }
     return VDB_OK;
@@ -1481,10 +1760,21 @@ int vdb_get_stat(vdb_t* h, const char* name, int64_t* value) {
   if (!strcmp(name, "rows")) { *value = h->n; return VDB_OK; }
   if (!strcmp(name, "n_shards")) { *value = is_sharded(h) ? (int64_t)h->shards.size() : 1; return VDB_OK; }
   if (!strcmp(name, "scratch_bytes")) { *value = (int64_t)kNaScratchBytes; return VDB_OK; }
+  if (!strcmp(name, "workspace_allocs")) { *value = h->n_ws_allocs; for (vdb_t* c : h->shards) *value += c->n_ws_allocs; return VDB_OK; }
   if (is_sharded(h)) {
     if (!strcmp(name, "rows_per_shard")) { *value = h->per; return VDB_OK; }
     if (!strcmp(name, "capacity_rows")) { *value = 0; for (vdb_t* c : h->shards) *value += c->cap; return VDB_OK; }
     if (!strcmp(name, "p2p_direct_shards")) { *value = 0; for (char d : h->shard_direct) *value += d; return VDB_OK; }
+    if (!strncmp(name, "sharded_issue_phase_", 20) && name[20] >= '0' && name[20] <= '7') {   // ns per call since the last read of sharded_issue_ns_avg
+      *value = h->issue_calls ? h->issue_phase_ns[name[20] - '0'] / h->issue_calls : 0;
+      return VDB_OK;
+    }
+    if (!strcmp(name, "sharded_issue_ns_avg")) {
+      for (int64_t& v : h->issue_phase_ns) v = 0;   // mean host time per sharded search since the last read
+      *value = h->issue_calls ? h->issue_ns_sum / h->issue_calls : 0;
+      h->issue_ns_sum = 0; h->issue_calls = 0;
+      return VDB_OK;
+    }
     const int rc = vdb_get_stat(h->shards[0], name, value);   // everything else: shard 0's
     return rc ? fail(h, rc, h->shards[0]->err) : VDB_OK;
   }
@@ -1548,11 +1838,48 @@ int vdb_get_stat(vdb_t* h, const char* name, int64_t* value) {
       const double v = rd ? (double)n16 * 16 / (ms * 1e-3) / 1e6 : (double)h->n_cu * 8 * iters * (m16 ? 16 * 16384.0 : 8 * 32768.0) / (ms * 1e-3) / 1e9;
       best = std::max(best, v);
     }
+    if (rd && h->scan_balance == 1 && h->w_ticket.p) {
+      // ... and in the fused scan's partition: the tile ranges its self-tuned per-XCD shares deal out (scan_fused.h; the
+      // same formula on the same share table), so the figure stays a ceiling for a scan that balances its XCDs
+      const int n_blocks = gemv_grid(h);
+      const int n_cu = std::max(8, h->n_cu & ~7);
+      const int rounds = std::min(kFusedMaxRounds, (n_blocks + n_cu - 1) / n_cu), n_groups = 8 * rounds;
+      unsigned share[8 * kFusedMaxRounds] = {};
+      HIP_TRY(h, hipDeviceSynchronize());
+      HIP_TRY(h, hipMemcpy(share, (unsigned*)h->w_ticket.p + kFusedShareOffset, sizeof share, hipMemcpyDeviceToHost));
+      auto group_blocks = [&](int g) {
+        const int r = g >> 3, lo = r * n_cu, hi = r == rounds - 1 ? n_blocks : std::min(n_blocks, lo + n_cu);
+        return std::max(0, (hi - lo - (g & 7) + 7) >> 3);
+      };
+      const long long n_tiles = (long long)(n16 / (12 * 64));
+      std::vector<long long> before(n_groups + 1, 0);
+      for (int g = 0; g < n_groups; ++g) before[g + 1] = before[g] + (long long)(share[g] ? share[g] : kFusedShareUnit) * group_blocks(g);
+      std::vector<ProbeRange> rg((size_t)n_blocks);
+      for (int b = 0; b < n_blocks; ++b) {
+        const int round = std::min(b / n_cu, rounds - 1), grp = (b & 7) + 8 * round;
+        rg[(size_t)b] = ProbeRange{n_tiles * before[grp] / before[n_groups], n_tiles * before[grp + 1] / before[n_groups],
+                                   (long long)((b - round * n_cu) >> 3) * 4, (long long)group_blocks(grp) * 4};
+      }
+      if ((rc = ensure(h, h->w_idx, rg.size() * sizeof(ProbeRange)))) return rc;
+      HIP_TRY(h, hipMemcpy(h->w_idx.p, rg.data(), rg.size() * sizeof(ProbeRange), hipMemcpyHostToDevice));
+      for (int rep = 0; rep < 5; ++rep) {
+        HIP_TRY(h, hipEventRecord(e0, h->stream));
+        hipLaunchKernelGGL((probe_read_ranges_kernel<12>), dim3(n_blocks), dim3(256), 0, h->stream, (const v4u_t*)src, (const ProbeRange*)h->w_idx.p, (unsigned*)h->w_thr.p);
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipEventRecord(e1, h->stream));
+        HIP_TRY(h, hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIP_TRY(h, hipEventElapsedTime(&ms, e0, e1));
+        if (rep == 0 || ms <= 0.f) continue;
+        best = std::max(best, (double)n_tiles * 12 * 1024 / (ms * 1e-3) / 1e6);
+      }
+    }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     *value = (int64_t)best;
     return VDB_OK;
   }
+  if (!strcmp(name, "last_fused")) { *value = h->last_fused; return VDB_OK; }
   if (!strcmp(name, "mfma_last_skipped_tiles")) { *value = h->mfma_last_skipped; return VDB_OK; }
   if (!strncmp(name, "scan_share_", 11)) {   // the fused scan's self-tuned share of block group g (1024 = equal)
     const long g = strtol(name + 11, nullptr, 10);

@@ -76,6 +76,14 @@ class FlatIndex:
     def reserve(self, n_rows: int) -> None:
         self._chk(self._lib.vdb_reserve(self._h, int(n_rows)))
 
+    def rebalance(self, total_rows: int) -> None:
+        """Re-partition a row-sharded index for total_rows rows (rows move device to device, bits verbatim)."""
+        self._chk(self._lib.vdb_rebalance(self._h, int(total_rows)))
+
+    def warm(self, max_batch: int, k: int, rerank_kprime: int = 0) -> None:
+        """Pre-size the workspaces of searches up to max_batch queries, so none grows inside a later search."""
+        self._chk(self._lib.vdb_warm(self._h, int(max_batch), int(k), int(rerank_kprime)))
+
     def set_row_offset(self, off: int) -> None:
         self._chk(self._lib.vdb_set_row_offset(self._h, int(off)))
 

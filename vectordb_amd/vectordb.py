@@ -18,7 +18,7 @@ implemented in `bidirectional_rerank` below.
 from __future__ import annotations
 
 import re
-from typing import Any, Callable, Dict, List, Optional, Tuple
+from typing import Any, Callable, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 import pandas as pd
@@ -150,12 +150,13 @@ class ProductVectorDB:
     def __init__(self, persist_directory: str = None, collection_name: str = config.COLLECTION_NAME,
                  embedding_model_name: str = config.EMBEDDING_MODEL, *, embed_fn: Optional[Callable] = None,
                  usda_lookup_map: Optional[Dict[str, str]] = None, dtype: str = None, device: int = None,
-                 lib=None, client: Optional[PersistentClient] = None):
+                 lib=None, client: Optional[PersistentClient] = None, devices: Optional[Sequence[int]] = None,
+                 expected_rows: Optional[int] = None):
         self.persist_directory = str(config.CHROMA_DB_PATH) if persist_directory is None else persist_directory
         self.collection_name = collection_name
         self.client = client if client is not None else PersistentClient(
             path=self.persist_directory, dtype=dtype or config.STORE_DTYPE,
-            device=config.DEVICE if device is None else device, lib=lib)
+            device=config.DEVICE if device is None else device, lib=lib, devices=devices, expected_rows=expected_rows)   # devices=[...]: row-sharded over those GPUs
         self.embedder = ProductEmbedder(model_name=embedding_model_name, embed_fn=embed_fn)
         self.usda_lookup_map = build_usda_lookup() if usda_lookup_map is None else dict(usda_lookup_map)
         self.collection = self._open_collection()
