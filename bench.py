@@ -7,6 +7,11 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
+For N > 1 the line also carries `inproc_sharded`: the same workload through ONE vdb_create_sharded handle over the same
+GPUs (one process, P2P result stores, no collective), run in a child process once the ranks have released their shards
+(--no-inproc skips it; --inproc adds it at N = 1).  --backend gloo --device-map 0,0 runs two ranks on one GPU
+(diagnostic: it exercises the multi-rank code path where no second GPU exists).
+
 A "step" is one pass of the hot path over one query batch: normalise the queries,
 scan the (row-sharded) corpus with the fused top-k' kernel, merge, fp32 rerank,
 and for N>1 one RCCL all-gather + on-device merge.  The corpus (10M rows in
@@ -60,7 +65,19 @@ def parse_args():
     ap.add_argument("--mfma-split", type=int, default=0, help="diagnostic: mfma_split_x1000 option")
     ap.add_argument("--ablate", type=int, default=0, help="diagnostic: MFMA kernel ablation bits (results invalid)")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE", help="diagnostic: vdb_set_option on the local shard")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend of the N > 1 exchange: nccl (= RCCL over xGMI, the measured path) or gloo (diagnostic: "
+                         "the all-gather goes through host memory; lets the multi-rank code path run where RCCL cannot, e.g. two ranks on one GPU)")
+    ap.add_argument("--device-map", default="", metavar="D0,D1,...", help="diagnostic: rank r uses GPU D[r] (default: its LOCAL_RANK); '0,0' runs two ranks on one GPU")
+    ap.add_argument("--inproc", action="store_true", help="also time the ONE-process form (vdb_create_sharded over the same GPUs, P2P result stores, no collective) "
+                                                          "in a child process and report it as `inproc_sharded` (default when --gpus > 1)")
+    ap.add_argument("--no-inproc", action="store_true")
+    ap.add_argument("--inproc-child", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
+
+
+def device_map(args):
+    return [int(x) for x in args.device_map.split(",") if x.strip() != ""]
 
 
 def self_launch(args):
@@ -68,7 +85,7 @@ def self_launch(args):
     relay its exit code.  Nothing in this process has touched the GPU yet (device_count() does not initialise it)."""
     import torch
     have = torch.cuda.device_count()
-    if have < args.gpus:
+    if have < args.gpus and not device_map(args):
         raise SystemExit(f"--gpus {args.gpus} but this node shows {have} GPU(s)")
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -196,6 +213,102 @@ def traffic_pass(args):
         shutil.rmtree(d, ignore_errors=True)
 
 
+def run_inproc_child(args, world):
+    """`python bench.py --inproc-child ...` as a child process with a time limit -> its JSON block, or {"error": ...}."""
+    import signal
+    cmd = [sys.executable, os.path.abspath(__file__), "--inproc-child", "--gpus", str(world), "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--rows", str(args.rows), "--dim", str(args.dim), "--batch", str(args.batch), "--batch2", str(args.batch2), "--steps2", str(args.steps2),
+           "--k", str(args.k), "--kprime", str(args.kprime), "--dtype", args.dtype, "--seed", str(args.seed), "--time-every", str(args.time_every)]
+    if args.device_map:
+        cmd += ["--device-map", args.device_map]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID",
+                                                             "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE", "GROUP_WORLD_SIZE", "ROLE_WORLD_SIZE")}
+    try:
+        p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, start_new_session=True)
+        try:
+            so, se = p.communicate(timeout=180)
+        except subprocess.TimeoutExpired:
+            os.killpg(p.pid, signal.SIGKILL)
+            p.communicate()
+            return {"error": "the one-process sharded run did not finish in 180 s"}
+        lines = [ln for ln in so.decode("utf-8", "replace").splitlines() if ln.startswith("{")]
+        if p.returncode != 0 or not lines:
+            return {"error": f"the one-process sharded run exited with {p.returncode}: " + se.decode("utf-8", "replace")[-400:]}
+        return json.loads(lines[-1])
+    except (OSError, ValueError) as e:
+        return {"error": f"the one-process sharded run could not be started or read: {e}"}
+
+
+def inproc_child(args):
+    """The one-process form of the same workload: ONE vdb_create_sharded handle over the N GPUs, queries
+    and results on shard 0's device, every shard's last block storing its k results into shard 0's gather buffer (P2P over
+    xGMI), one merge kernel — no torch.distributed, no collective.  Prints one JSON block."""
+    import numpy as np
+    import torch
+    from vectordb_amd import FlatIndex, SynthSpec
+    from vectordb_amd.synth import query_source_row
+    g = args.gpus
+    dmap = device_map(args)
+    devices = [dmap[r % len(dmap)] for r in range(g)] if dmap else list(range(g))
+    n, dim, k = args.rows, args.dim, args.k
+    kp = args.kprime if args.dtype == "bf16" else 0
+    spec = SynthSpec(seed=args.seed, kind=1, n_clusters=args.clusters or max(1, int(np.sqrt(n))), noise=0.3)
+    qspec = SynthSpec(seed=args.seed + 1, kind=2, noise=0.5, base_kind=1, base_seed=args.seed, base_n=n,
+                      base_n_clusters=spec.n_clusters, base_noise=0.3)
+    torch.cuda.set_device(devices[0])
+    dev = torch.device("cuda", devices[0])
+    ix = FlatIndex(dim, args.dtype, True, devices=devices)
+    ix.reserve(n)
+    ix.add_synth(0, n, spec)
+    out = {"n_shards": g, "devices": devices, "p2p_direct_shards": ix.get_stat("p2p_direct_shards"), "rows_per_shard": ix.get_stat("rows_per_shard"),
+           "exchange": "each shard's finish stores its k results into shard 0's gather buffer (P2P over xGMI; a peer copy without peer access), one merge kernel on shard 0"}
+    st = torch.cuda.current_stream(dev).cuda_stream
+    for b, steps, label in ((args.batch, args.steps, "batch%d" % args.batch), (args.batch2, max(1, min(args.steps, args.steps2)), "batch%d" % args.batch2)):
+        if not b or (label in out):
+            continue
+        n_sets = 16 if b > 1 else 64
+        qpool = torch.empty((n_sets, b, dim), dtype=torch.float32, device=dev)
+        for s_ in range(n_sets):
+            ix.synth_rows_device(qpool[s_].data_ptr(), s_ * b, b, qspec, st)
+        oi = [torch.empty((b, k), dtype=torch.int64, device=dev) for _ in range(4)]
+        od = [torch.empty((b, k), dtype=torch.float32, device=dev) for _ in range(4)]
+        ix.warm(b, k, kp)
+        ix.set_option("timing_every", max(1, args.time_every))
+
+        def step(i):
+            ix.search_device(qpool[i % n_sets].data_ptr(), b, k, kp, oi[i & 3].data_ptr(), od[i & 3].data_ptr(), st)
+
+        for i in range((150 if b <= 64 else 8) + args.warmup):
+            step(i)
+        torch.cuda.synchronize(dev)
+        for d in set(devices):
+            torch.cuda.synchronize(d)
+        ix.get_stat("sharded_issue_ns_avg")
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i)
+        t_host = time.perf_counter() - t0
+        torch.cuda.synchronize(dev)
+        elapsed = time.perf_counter() - t0
+        issue_us = ix.get_stat("sharded_issue_ns_avg") / 1e3
+        lat = []
+        for i in range(min(steps, 100)):
+            t1 = time.perf_counter()
+            step(i)
+            torch.cuda.synchronize(dev)
+            lat.append((time.perf_counter() - t1) * 1e3)
+        last = (min(steps, 100) - 1) % n_sets
+        idx_h, dist_h = oi[(min(steps, 100) - 1) & 3].cpu().numpy(), od[(min(steps, 100) - 1) & 3].cpu().numpy()
+        src = np.array([query_source_row(qspec, last * b + j) for j in range(min(b, 8))])
+        out[label] = {"value": steps * b / elapsed, "unit": "queries/s", "ms_per_step": 1e3 * elapsed / steps, "steps": steps,
+                      "host_issue_ms_per_step": 1e3 * t_host / steps, "library_host_us_per_call": issue_us,
+                      "sync_latency_ms": {"median": float(np.median(lat)), "p99": float(np.sort(lat)[min(len(lat) - 1, int(0.99 * len(lat)))])},
+                      "planted_neighbour_first_and_ascending": bool(np.array_equal(idx_h[: len(src), 0], src)) and bool(np.all(np.diff(dist_h, axis=1) >= 0))}
+        del qpool
+    ix.close()
+    print(json.dumps(out), flush=True)
+
+
 def dist_rank0():
     return int(os.environ.get("RANK", "0")) == 0
 
@@ -267,7 +380,7 @@ def measure(sh, args, b, steps, warmup, qspec, device, world, n_local):
         lat.append((time.perf_counter() - t1) * 1e3)
     lat = np.sort(np.asarray(lat))
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -341,6 +454,8 @@ def measure(sh, args, b, steps, warmup, qspec, device, world, n_local):
 
 def main():
     args = parse_args()
+    if args.inproc_child:
+        return inproc_child(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -370,9 +485,13 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the engine has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    if world > 1 or (args.force_collective and "TORCHELASTIC_RUN_ID" in os.environ):
+    dmap = device_map(args)
+    dev_index = dmap[local_rank % len(dmap)] if dmap else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    if world > 1 and args.backend == "gloo":
+        dist.init_process_group("gloo")                          # diagnostic: the exchange goes through host memory
+    elif world > 1 or (args.force_collective and "TORCHELASTIC_RUN_ID" in os.environ):
         dist.init_process_group("nccl", device_id=device)        # the launcher's store (env://)
     elif args.force_collective:
         # (under the launcher a tcp:// init would look for the AGENT's store on that port and wait for ever)
@@ -423,7 +542,9 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": workload(args.batch),
                        "rows": n, "dim": dim, "batch": args.batch, "k": k, "kprime": kp, "rows_per_gpu": n_local,
-                       "parallelism": f"row-shard x{world} + all-gather merge" if world > 1 else "single GPU"},
+                       "parallelism": (f"row-shard x{world} + all-gather merge ({'RCCL' if args.backend == 'nccl' else 'gloo through host memory: diagnostic'})"
+                                       if world > 1 else "single GPU"),
+                       **({"device_map": dmap} if dmap else {})},
             "roofline": head["roofline"],
             "checks": head["checks"],
             "sync_latency_ms": head["sync_latency_ms"],
@@ -442,11 +563,20 @@ def main():
             blk["roofline"]["traffic_source"] = traffic_note if got or traffic is None else "the counter pass saw no launch of " + fam
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dim, k, n, args.seed)
+    sh.close()
+    del sh
+    torch.cuda.empty_cache()
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        # the P2P form next to the collective one.  The other ranks have released their shards and are
+        # leaving; the one-process handle over the same GPUs runs in a CHILD (a hang or fault there cannot take this
+        # line down: it is timed out and reported as an error string)
+        if (world > 1 or args.inproc) and not args.no_inproc:
+            out["inproc_sharded"] = run_inproc_child(args, world)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
-    sh.close()
-    if dist.is_initialized():
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

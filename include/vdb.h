@@ -144,9 +144,11 @@ int vdb_count(vdb_t* h, int64_t* n);
  * keeps k' >= k candidates that are re-scored in fp32 against the fp32 copy
  * (the GPU analogue of src/vectordb.py:282-314) — or, on a bf16 store created
  * WITHOUT the fp32 copy (2 bytes per element: 100M x 768 rows fit one GPU),
- * against the stored bf16 rows with the fp32 query: the answer is then that of
- * rerank_kprime = 0 (the exact top-k of <fp32 query, bf16 row>), but batches may
- * take the batched MFMA kernels instead of ceil(b/4) scan passes.  Outputs: b x k,
+ * against the stored bf16 rows with the fp32 query: on the GEMV scan the answer
+ * is then that of rerank_kprime = 0 (the exact top-k of <fp32 query, bf16 row>);
+ * batches may take the batched MFMA kernels instead of ceil(b/4) scan passes, which
+ * choose the k' candidates from bf16-rounded QUERIES — the same answer within the
+ * k' candidate limit described below (near-duplicate clusters larger than k').  Outputs: b x k,
  * padded with idx -1 / dist +inf when fewer than k rows exist.
  * Precision: an fp32 store, and a bf16 store with a rerank, return fp32 cosines of the stored fp32 rows whatever the
  * batch size.  A bf16 store searched WITHOUT a rerank returns the exact top-k of <fp32 query, bf16 row> scores; it
@@ -177,7 +179,11 @@ int vdb_search_dev(vdb_t* h, const float* queries_dev, int b, int k, int rerank_
                    int64_t* out_idx_dev, float* out_dist_dev, void* stream);
 
 /* vdb_search_dev for callers that cannot call hipMalloc: code under HIP graph capture, tight serving loops, harnesses
- * that forbid allocation.  NO COUNTERPART IN THE REFERENCE.  Same inputs, outputs and results as vdb_search_dev, but
+ * that forbid allocation.  NO COUNTERPART IN THE REFERENCE.  Same inputs and outputs as vdb_search_dev.  Results:
+ * identical (bit for bit) whenever vdb_search_dev runs the GEMV scan itself; where vdb_search_dev would take the batched
+ * MFMA kernels (bf16 store with a rerank, from 3 queries on a large store), equal up to the k' candidate limit — this
+ * entry point picks its k' candidates with fp32 queries, the batched kernels with bf16-rounded ones, which differ only
+ * inside near-duplicate clusters larger than k' (tests/test_zz_no_alloc.py pins both statements).  Here
  * the search always runs on the GEMV scan and its workspaces (normalised queries, partial top-k' lists) come out of a
  * fixed array in device memory that the library holds per GPU (2.3 MiB, "scratch_bytes" in vdb_get_stat) instead of
  * the handle's grown-on-demand buffers: the call makes no hipMalloc/hipFree and creates no event.  Limits (beyond

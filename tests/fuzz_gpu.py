@@ -202,13 +202,36 @@ def state_case(rng, case):
         for step in range(int(rng.integers(6, 14))):
             n = hx.count()
             assert n == ox.count(), what0 + " count"
-            op = str(rng.choice(["add", "add", "search", "search", "masked", "fetch", "selfjoin", "reopen"]))
+            op = str(rng.choice(["add", "add", "add_dev", "search", "search", "masked", "fetch", "selfjoin", "reopen", "rebalance", "warm", "remote"]))
             what = what0 + f" step {step} {op} n={n} after {log}"
             if op == "add" or n == 0:
                 m = int(rng.choice([1, 7, 255, 256, 257, 1000, 4097]))
                 rows = base[rng.integers(0, 61, m)] + 0.4 * rng.standard_normal((m, dim)).astype(np.float32)
                 hx.add(rows); ox.add(rows)
                 log.append(f"add{m}")
+                continue
+            if op == "add_dev":                       # rows resident on the (first) GPU; a sharded handle routes them by span
+                import torch
+                m = int(rng.choice([1, 300, 2049]))
+                rows = base[rng.integers(0, 61, m)] + 0.4 * rng.standard_normal((m, dim)).astype(np.float32)
+                t = torch.from_numpy(rows).cuda()
+                torch.cuda.synchronize()
+                hx.add_device(t.data_ptr(), m); ox.add(rows)
+                log.append(f"addd{m}")
+                continue
+            if op == "rebalance":                     # re-partition (a no-op on the plain handle): answers must not change
+                tot = int(rng.choice([1, n, 2 * n, 5 * n + 1000]))
+                hx.rebalance(tot); ox.rebalance(tot)
+                log.append(f"reb{tot}")
+                continue
+            if op == "warm":
+                hx.warm(int(rng.choice([1, 5, 70, 300])), 10, 40 if dtype == "bf16" else 0)
+                log.append("warm")
+                continue
+            if op == "remote":                        # from here on the shards behave as if on GPUs without peer access
+                if g:
+                    hx.set_option("shard_force_remote", int(rng.integers(0, 2)))
+                    log.append("remote")
                 continue
             kp_ok = dtype == "bf16"
             k = int(rng.choice([1, 5, 10, 40]))
@@ -220,7 +243,7 @@ def state_case(rng, case):
             if op == "search":
                 _same_answer(hx.search(q, k, kp), ox.search(q, k, kp), what + f" b={b} k={k} kp={kp}")
                 log.append(f"s{b}")
-            elif op == "masked" and not g:
+            elif op == "masked":
                 mask = rng.random(n) < float(rng.choice([0.02, 0.5, 1.0]))
                 _same_answer(hx.search_masked(q, k, mask, kp), ox.search_masked(q, k, mask, kp), what + f" b={b} k={k} kp={kp}")
                 log.append(f"m{b}")
@@ -229,7 +252,7 @@ def state_case(rng, case):
                 a, r = hx.fetch(idx), ox.fetch(idx)
                 assert np.max(np.abs(a.view(np.int32).astype(np.int64) - r.view(np.int32).astype(np.int64))) <= 1, what   # <= 1 ulp
                 log.append("f")
-            elif op == "selfjoin" and not g and n >= 2:
+            elif op == "selfjoin" and n >= 2:
                 q0 = int(rng.integers(0, n)); qn_ = int(rng.integers(1, min(200, n - q0) + 1))
                 ex = bool(rng.integers(0, 2))
                 _same_answer(hx.selfjoin(k, exclude_self=ex, rerank_kprime=kp, q_row0=q0, q_n=qn_),

@@ -632,6 +632,7 @@ def test_mfma_last_pass_skips_the_sampled_tiles(hip_lib, oracle_mod, corpus20k, 
     ix = FlatIndex(dim, "bf16", True)
     ix.add_synth(0, n, spec)
     ix.set_option("mfma_cost_model", 0)
+    ix.set_option("mfma_dense_tiles", 16)                      # (round 3's default sample, 64 tiles, would cover this small store in one pass)
     ix.set_option("mfma_append_cap", 512)                      # R = 512/(4*40) = 3.2 -> dense sample, 36-tile sample at stride 2, rest
     out = {}
     for skip in (1, 0):

@@ -66,7 +66,8 @@ def test_stream_kernel_multi_pass_and_selfjoin(hip_lib, oracle_mod):
     queries = oracle_mod.synth_rows(0, 40, dim, qspec)
     ix = FlatIndex(dim, "bf16", True)
     ix.set_option("mfma_cost_model", 0)
-    ix.set_option("mfma_append_cap", 4096)      # smaller candidate buffers -> the protocol takes two append passes at this size
+    ix.set_option("mfma_append_cap", 4096)      # smaller candidate buffers ...
+    ix.set_option("mfma_one_pass_span", 2)      # ... and no single-pass shortcut: the protocol takes two append passes at this size (1 172 tiles, 64 of them in the dense sample)
     ix.add_synth(0, n, spec)
     idx, dist = ix.search(queries, 10, 40)
     assert ix.get_stat("last_path") == 6 and ix.get_stat("mfma_last_overflow") == 0

@@ -85,3 +85,27 @@ def test_noalloc_other_shapes_and_a_second_handle(hip_lib, oracle_mod):
     assert np.all(oi == -1) and np.all(np.isinf(od))
     for ix in (a, b, e):
         ix.close()
+
+
+def test_noalloc_against_the_batched_kernels(hip_lib, oracle_mod):
+    """The header's contract where vdb_search_dev does NOT run the GEMV scan: with the cost model off, 8 queries on a
+    bf16 + rerank store take the batched MFMA path (bf16-rounded queries pick the k' candidates); the entry point that
+    allocates nothing stays on the scan (fp32 queries).  On data without near-duplicate clusters larger than k' both
+    return the same rows, with fp32 distances of those rows."""
+    import torch
+    n, dim = 50_021, 768
+    spec = SynthSpec(seed=606, kind=1, n_clusters=223, noise=0.3)
+    qspec = SynthSpec(seed=607, kind=2, noise=0.5, base_kind=1, base_seed=606, base_n=n, base_n_clusters=223, base_noise=0.3)
+    ix = FlatIndex(dim, "bf16", True)
+    ix.add_synth(0, n, spec)
+    ix.set_option("mfma_cost_model", 0)
+    queries = torch.from_numpy(oracle_mod.synth_rows(0, 8, dim, qspec)).cuda()
+    oi, od, ri, rd = _both(ix, queries, 8, 10, 40)
+    assert ix.get_stat("last_path") == 0                      # the last call (noalloc): the scan
+    st = torch.cuda.current_stream().cuda_stream
+    ix.search_device(queries.data_ptr(), 8, 10, 40, torch.empty((8, 10), dtype=torch.int64, device="cuda").data_ptr(),
+                     torch.empty((8, 10), dtype=torch.float32, device="cuda").data_ptr(), st)
+    torch.cuda.synchronize()
+    assert ix.get_stat("last_path") == 6                      # vdb_search_dev: the streaming MFMA kernel
+    assert np.array_equal(oi, ri) and np.allclose(od, rd, rtol=1e-5, atol=2e-6)
+    ix.close()

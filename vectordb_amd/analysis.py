@@ -3,7 +3,7 @@
 Each harness keeps the reference's bookkeeping and output columns but replaces N
 sequential batch-1 `collection.query` calls by ONE batched query (which the
 engine serves on MFMA wherever its cost model finds that faster than GEMV passes —
-from 2 queries on at 10M bf16 rows; small stores like the reference's stay on the scan):
+from 3 queries on at 10M bf16 rows (two stay on the scan, which is faster there); small stores like the reference's stay on the scan):
 
   evaluate_usda_classification    analysis/run_bidirectional_test.py:164-268
   classify_products_by_usda_code  analysis/run_bidirectional_test.py:115-161

@@ -97,20 +97,22 @@ hipError_t mfma_search_launch(const MfSearchArgs& a, int* skipped_tiles) {
   };
 
   // pass 0: dense scores of a strided 16-tile sample -> t0 = a lower bound of the k'-th best per query
-  long long t_cur = std::min<long long>(n_tiles, kMf3DenseTiles);
+  long long t_cur = std::min<long long>(n_tiles, std::max(1, std::min(a.dense_tiles, kMf3DenseTiles)));
   {
     const int stride = (int)std::max<long long>(1, n_tiles / t_cur);
     MF_TRY(launch_pass(0, t_cur, stride, 0));
     // rows of the dense matrix beyond the sampled tiles were never written: select over t_cur*256 columns only
     // n_tiles == t_cur: the dense pass saw the whole store and the next pass is the last; either way a valid lower bound suffices
-    hipLaunchKernelGGL(dense_lower_bound_kernel, dim3(b), dim3(64), 0, st, dense, kMf3DenseLd, (int)t_cur * kMfBM, kk, thr, cand_cnt);   // also clears the append counters
+    hipLaunchKernelGGL(dense_lower_bound_kernel, dim3(b), dim3(256), 0, st, dense, kMf3DenseLd, (int)t_cur * kMfBM, kk, thr, cand_cnt);   // also clears the append counters
     MF_TRY(hipGetLastError());
   }
   // append passes over geometrically growing strided samples; the growth factor per pass is
   // at most R = cap/(4 k') so that ~cap/4 candidates per query are expected in each
   const double Rmax = std::max<double>(2.0, (double)cap / (4.0 * kk));
   const double span = (double)n_tiles / (double)t_cur;
-  const int n_pass = span <= 1.0 ? 1 : std::max(1, (int)std::ceil(std::log(span) / std::log(Rmax) - 0.15));   // up to ~2x Rmax per pass
+  int n_pass = span <= 1.0 ? 1 : std::max(1, (int)std::ceil(std::log(span) / std::log(Rmax) - 0.15));   // up to ~2x Rmax per pass
+  // one pass means k' x span hits per query in it, two about 2 k' sqrt(span) at the price of a sample pass and a selection
+  if (n_pass == 1 && span > (double)a.one_pass_span) n_pass = 2;
   const double growth = std::pow(span, 1.0 / n_pass);
   // Two passes (the usual case): the last one leaves out the tiles the sample pass multiplied and the final
   // selection is seeded with the sample's sorted list instead — the sample is 2 % of the tiles at 10M rows,

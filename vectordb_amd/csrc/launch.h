@@ -54,6 +54,8 @@ struct MfSearchArgs {
   const unsigned char* rows_bf16; int n_rows; const float* qn; int b; int kk; int self0;
   int n_cu; int variant;           // 4 = 256x128 warp-specialised, 5 = 256x256 wide tile, 6 = streaming (<= 64 queries)
   int cap; int split_x1000; int skip_sample; int force_fallback; int ablate; int stream_nt;
+  int one_pass_span;               // stores up to this many times the dense sample are searched in ONE append pass
+  int dense_tiles;                 // 256-row tiles of the dense sample that gives the first threshold (<= 64)
   unsigned char* qb16;             // [b_pad][768] bf16
   float* cand_s; int* cand_i;      // [b][cap]
   int* cand_cnt;                   // [b] counters, kMfCntStrideC ints apart, + the overflow flag behind them
@@ -65,7 +67,7 @@ struct MfSearchArgs {
   hipStream_t st;
 };
 struct MfPlan { int variant; int n_qt; int b_pad; int n_qt_fb; int fb_splits; };
-constexpr int kMfDenseLdC = 4096;       // floats per query of the dense sample (16 tiles x 256 rows; k_mfma.hip asserts it)
+constexpr int kMfDenseLdC = 32768;      // floats per query of the dense sample's buffer (up to 128 tiles x 256 rows; k_mfma.hip asserts it)
 constexpr int kMfCntStrideC = 32;        // ints between two queries' append counters (one cache line each)
 constexpr int kMfRowBytesC = 1536;      // the batched path serves 768-d bf16 rows
 constexpr int kMfMaxQueriesPerCall = 4096;   // mfma_search_launch serves at most this many queries (the caller chunks)

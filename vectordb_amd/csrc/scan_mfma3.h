@@ -26,7 +26,7 @@
 
 namespace vdbk {
 
-constexpr int kMf3DenseTiles = 16;                     // dense sample: 16 tiles = 4096 rows
+constexpr int kMf3DenseTiles = 128;                    // dense sample: at most 128 tiles = 32768 rows (the search picks 64 or 128 by store size; round 2: 16)
 constexpr int kMf3DenseLd = kMf3DenseTiles * kMfBM;
 
 #ifdef VDB_MFMA_HOST_TU   // kernels of the orchestrating TU (k_mfma.hip) only: every pass-kernel TU includes this header
@@ -59,12 +59,26 @@ __global__ __launch_bounds__(NW * 64) void select_kth_kernel(const float* __rest
   const int* ci = cand_i ? cand_i + (size_t)q * cap_or_n : nullptr;
   WaveTopK<1> tk;
   tk.init(kk);
-  for (int base = w * 64; base < n; base += NW * 64) {
-    const int i = base + lane;
-    const bool valid = i < n;
-    const float s = valid ? cs[i] : -INFINITY;
-    const int id = valid ? (ci ? ci[i] : i) : kIdxSentinel;
-    tk.push_lanes_bulk(s, id, valid && s > -INFINITY);
+  // kSelAhead chunks of 64 candidates per wave are loaded together (unconditional loads at clamped positions: a branch
+  // around a load makes the compiler wait for each on its own, and the loop was a chain of ~1 us round trips — 25 us
+  // for the 5 000 candidates per query of a sample pass at an 8-GPU shard's size)
+  constexpr int kSelAhead = 8;
+  for (int base0 = w * 64; base0 < n; base0 += kSelAhead * NW * 64) {
+    float ps[kSelAhead];
+    int pi[kSelAhead];
+#pragma unroll
+    for (int u = 0; u < kSelAhead; ++u) {
+      const int i = min(base0 + u * NW * 64 + lane, n - 1);
+      ps[u] = cs[i];
+      pi[u] = ci ? ci[i] : i;
+    }
+#pragma unroll
+    for (int u = 0; u < kSelAhead; ++u) {
+      const int base = base0 + u * NW * 64;
+      if (base >= n) break;   // wave-uniform
+      const bool valid = base + lane < n;
+      tk.push_lanes_bulk(valid ? ps[u] : -INFINITY, valid ? pi[u] : kIdxSentinel, valid && ps[u] > -INFINITY);
+    }
   }
   // per-wave lists are sorted: tree-merge with the bitonic wave merge
   {
@@ -91,24 +105,46 @@ __global__ __launch_bounds__(NW * 64) void select_kth_kernel(const float* __rest
 // score of an actual sampled row with at least kk sampled rows at or above it, hence <= the true k'-th best.  A little
 // looser than the exact k'-th best of the sample but ~10x cheaper than an exact selection over the dense scores
 // (127 us at B = 1024).  Also clears the query's append counter for the first append pass.
-__global__ __launch_bounds__(64) void dense_lower_bound_kernel(const float* __restrict__ scores, int ld, int n, int kk,
-                                                               float* __restrict__ thr_out, int* __restrict__ cand_cnt) {
-  // kk-th largest of 256 strided group maxima (4 per lane; groups of 16 at n = 4096): about 1.06 % of a query's scores
-  // lie above it, against 0.98 % for the exact kk-th best of the sample (kk = 40) - and 1.5 % for the 64 group maxima
-  // this kernel used first: a third fewer hits in the sample pass, which is bound by its appends.
-  constexpr int G = 4;
+__global__ __launch_bounds__(256) void dense_lower_bound_kernel(const float* __restrict__ scores, int ld, int n, int kk,
+                                                                float* __restrict__ thr_out, int* __restrict__ cand_cnt) {
+  // kk-th largest of 256 strided group maxima (4 per lane; groups of 16 at n = 4096, of 64 at n = 16384): about 1.06 % of
+  // a 4096-row sample's scores lie above it, against 0.98 % for the exact kk-th best of the sample (kk = 40) - and 1.5 % for
+  // the 64 group maxima this kernel used first: a third fewer hits in the sample pass, which is bound by its appends.
+  // Four waves per query: wave w reads the 256-column slices w, w + 4, ... (n is a whole number of them: tiles of 256 rows),
+  // all its loads in flight together (unconditional, at clamped slice numbers: a repeated slice does not change a maximum;
+  // the one-wave form with a bounds test per load was a chain of round trips, 18 us for 32 queries), and wave 0 folds
+  // the four partial maxima and bisects.
+  constexpr int G = 4, kSlicesPerWave = kMf3DenseTiles / 4;
+  __shared__ float part[3][G][64];
   const int q = blockIdx.x;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const float* cs = scores + (size_t)q * ld;
+  const int n_slices = n >> 8;
   float v[G];
 #pragma unroll
   for (int g = 0; g < G; ++g) v[g] = -INFINITY;
-  for (int i0 = 0; i0 < n; i0 += 64 * G)
+  if (n_slices > 0) {
+    float x[kSlicesPerWave][G];
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-      const int i = i0 + 64 * g + lane;
-      if (i < n) v[g] = fmaxf(v[g], cs[i]);
+    for (int t = 0; t < kSlicesPerWave; ++t) {
+      const int sl = min(w + 4 * t, n_slices - 1);
+#pragma unroll
+      for (int g = 0; g < G; ++g) x[t][g] = cs[sl * 256 + 64 * g + lane];
     }
+#pragma unroll
+    for (int t = 0; t < kSlicesPerWave; ++t)
+#pragma unroll
+      for (int g = 0; g < G; ++g) v[g] = fmaxf(v[g], x[t][g]);
+  }
+  for (int i = (n_slices << 8) + threadIdx.x; i < n; i += 256) v[0] = fmaxf(v[0], cs[i]);   // (a ragged tail: not produced by the protocol, kept for safety)
+  if (w > 0) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) part[w - 1][g][lane] = v[g];
+  }
+  __syncthreads();
+  if (w > 0) return;
+#pragma unroll
+  for (int g = 0; g < G; ++g) v[g] = fmaxf(fmaxf(v[g], part[0][g][lane]), fmaxf(part[1][g][lane], part[2][g][lane]));
   // keys in unsigned order; the kk-th largest by bisection over the 32 key bits (counts by ballot)
   unsigned u[G];
 #pragma unroll

@@ -93,6 +93,8 @@ struct vdb {
   DevBuf w_seed_s, w_seed_i;      // the sample pass's sorted list (seeds the final selection)
   DevBuf w_fb_s, w_fb_i;          // partial lists of the MFMA path's overflow fallback (never shared with a pending split scan)
   int mfma_skip_sample = 1;       // 1: the last of two passes leaves out the sample pass's tiles
+  int mfma_one_pass_span = 24;    // a store up to this many times the dense sample takes ONE append pass (round 2: up to 204 times: -20 % per 1024-query batch at 200k rows)
+  int mfma_dense_tiles = 0;       // tiles of the dense sample (first threshold): 0 = by store size, else 1..64
   void* pin = nullptr; size_t pin_bytes = 0;                                     // pinned host staging for small host-pointer searches
   DevBuf w_mask;                                                                // host-supplied eligibility bitmap (vdb_search_masked)
   int mfma_append_cap = 16384;   // candidate buffer entries per query (also sets how far a pass may grow: cap / 4k')
@@ -335,6 +337,11 @@ int mfma_search(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
   a.rows_bf16 = (const unsigned char*)h->rows_bf16; a.n_rows = n_rows; a.qn = qn; a.b = b; a.kk = kk;
   a.self0 = self_row0 >= 0 ? (int)self_row0 : -1;
   a.n_cu = h->n_cu; a.variant = h->mfma_variant; a.cap = cap; a.split_x1000 = h->mfma_split_x1000 ? h->mfma_split_x1000 : (pl.variant == 6 ? 600 : 500);
+  // the first threshold comes from a dense sample of D rows: the two append passes then see about 2 k' sqrt(rows / D) hits
+  // per query between them, and hits are what the pass kernels' epilogues pay for — 64 tiles (16 384 rows; 16 in round 2),
+  // 128 on large stores where the dense pass is small against the rest (profiles/r03_dense_sample_ab.txt)
+  a.dense_tiles = h->mfma_dense_tiles ? h->mfma_dense_tiles : (n_rows >= 6000000 ? 128 : 64);
+  a.one_pass_span = h->mfma_one_pass_span;
   a.skip_sample = h->mfma_skip_sample; a.force_fallback = h->mfma_force_fallback; a.ablate = h->mfma_ablate; a.stream_nt = h->stream_nt;
   a.qb16 = (unsigned char*)h->w_mfma.p;
   a.cand_s = (float*)h->w_cand_s.p; a.cand_i = (int*)h->w_cand_i.p; a.cand_cnt = (int*)h->w_cand_cnt.p;
@@ -1734,6 +1741,8 @@ int vdb_set_option(vdb_t* h, const char* name, int64_t value) {
     h->mfma_split_x1000 = (int)value; return VDB_OK;
   }
   if (!strcmp(name, "mfma_skip_sample")) { h->mfma_skip_sample = value != 0; return VDB_OK; }
+  if (!strcmp(name, "mfma_one_pass_span")) { h->mfma_one_pass_span = (int)std::max<int64_t>(1, std::min<int64_t>(value, 1 << 20)); return VDB_OK; }
+  if (!strcmp(name, "mfma_dense_tiles")) { if (value < 0 || value > 128) return fail(h, VDB_ERR_ARG, "mfma_dense_tiles must be 0 (by store size) or in [1,128]"); h->mfma_dense_tiles = (int)value; return VDB_OK; }
   if (!strcmp(name, "mfma_force_fallback")) { h->mfma_force_fallback = value != 0; return VDB_OK; }
   if (!strcmp(name, "mfma_append_cap")) {
     if (value < 256 || value > (1 << 22)) return fail(h, VDB_ERR_ARG, "mfma_append_cap must be in [256, 4194304]");

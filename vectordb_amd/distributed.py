@@ -140,6 +140,16 @@ class ShardedIndex:
             self.local.merge_topk_device(g_idx + 8 * b * k, g_idx, self.world, b, k, out_idx.data_ptr(),
                                          out_dist.data_ptr(), 0, dist_shard_stride=2 * words, idx_shard_stride=words)
             return out_idx, out_dist
+        if dist.get_backend(self.group) == "gloo":
+            # diagnostic form (bench.py --backend gloo): the collective runs on host copies of the packed results;
+            # the merge is the same kernel.  Synchronous — nothing here is a measured path.
+            torch.cuda.current_stream(self.device).synchronize()
+            host_all = torch.empty(self.world * words, dtype=torch.int64)
+            dist.all_gather_into_tensor(host_all, local.cpu(), group=self.group)
+            gathered.copy_(host_all)
+            self.local.merge_topk_device(g_idx + 8 * b * k, g_idx, self.world, b, k, out_idx.data_ptr(), out_dist.data_ptr(), st,
+                                         dist_shard_stride=2 * words, idx_shard_stride=words)
+            return out_idx, out_dist
         if self._side is None:
             self._side = torch.cuda.Stream(self.device)
         main = torch.cuda.current_stream(self.device)
