@@ -444,7 +444,12 @@ def measure(sh, args, b, steps, warmup, qspec, device, world, n_local):
         "value": steps * b / elapsed, "unit": "queries/s", "steps": steps, "warmup": warmup, "settle_steps_before_warmup": settle, "ms_per_step": 1e3 * elapsed / steps,
         "batch": b, "roofline": roof,
         "checks": {"planted_neighbour_first_and_ascending": planted_ok,
+                   # the bare-read probe (same launch shape and tile partition, no arithmetic) bounds the batched kernels; the
+                   # one-launch scan of round 3 streams 2-2.5 % FASTER than it (its FMAs space the waves' requests out; the probe
+                   # with one or two tiles in flight per wave, 2 or 4 blocks per CU, 25 launches each, tops out lower), so for
+                   # that kernel the probe is a reference point, not a ceiling: the vendor peak is the denominator that counts
                    "measured_peak_is_a_ceiling": (roof.get("frac_of_measured_peak") or 0) <= 1.02,
+                   "kernel_over_bare_read_probe": roof.get("frac_of_measured_peak"),
                    "mfma_overflow_fallback": sh.local.get_stat("mfma_last_overflow"),
                    "mfma_hits_per_query": sh.local.get_stat("mfma_last_hits") / b,
                    **({"prof": [sh.local.get_stat("mfma_prof_" + c) for c in "abcd"]} if args.ablate & 8 else {})},

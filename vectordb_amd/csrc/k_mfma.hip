@@ -77,9 +77,11 @@ hipError_t mfma_search_launch(const MfSearchArgs& a, int* skipped_tiles) {
   if (skipped_tiles) *skipped_tiles = 0;
   const MfGrid fb = mf_grid(a.n_cu, n_qt_fb, n_tiles, 64);
 
-  hipLaunchKernelGGL(queries_to_bf16_kernel, dim3(std::min(1024, (pl.b_pad * kMfDim + 255) / 256)), dim3(256), 0, st,
-                     a.qn, b, pl.b_pad, (uint16_t*)a.qb16, ovf);   // also clears the overflow flag
-  MF_TRY(hipGetLastError());
+  if (!a.qb16_ready) {
+    hipLaunchKernelGGL(queries_to_bf16_kernel, dim3(std::min(1024, (pl.b_pad * kMfDim + 255) / 256)), dim3(256), 0, st,
+                       a.qn, b, pl.b_pad, (uint16_t*)a.qb16, ovf);   // also clears the overflow flag
+    MF_TRY(hipGetLastError());
+  }
 
   // one pass of whichever kernel serves this batch; mode 0 = dense sample, 1 = append
   auto launch_pass = [&](int mode, long long pass_tiles, int stride, int skip_n) -> hipError_t {

@@ -57,6 +57,7 @@ struct MfSearchArgs {
   int one_pass_span;               // stores up to this many times the dense sample are searched in ONE append pass
   int dense_tiles;                 // 256-row tiles of the dense sample that gives the first threshold (<= 64)
   unsigned char* qb16;             // [b_pad][768] bf16
+  int qb16_ready;                  // != 0: the caller filled qb16 (and cleared the overflow flag) already
   float* cand_s; int* cand_i;      // [b][cap]
   int* cand_cnt;                   // [b] counters, kMfCntStrideC ints apart, + the overflow flag behind them
   float* thr;                      // [b]

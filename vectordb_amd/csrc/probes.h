@@ -20,13 +20,26 @@ __global__ __launch_bounds__(256) void probe_read_kernel(const v4u_t* __restrict
   const size_t gw = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (size_t)gridDim.x * 4;
   const size_t n_tiles = n16 / (U * 64);
   unsigned acc = 0;
-  for (size_t t = gw; t < n_tiles; t += nw) {
-    const v4u_t* q = p + t * (U * 64) + lane;
-    v4u_t v[U];
+  // the next tile's loads go out before this tile's are consumed (two tiles in flight per wave): a bare read that waited
+  // for each tile before asking for the next measured BELOW the scan, whose arithmetic overlaps its loads by itself
+  v4u_t cur[U], nxt[U];
+  size_t t = gw;
+  if (t < n_tiles) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(q + u * 64);
+    for (int u = 0; u < U; ++u) cur[u] = __builtin_nontemporal_load(p + t * (U * 64) + lane + u * 64);
+  }
+  for (; t < n_tiles; t += nw) {
+    const bool more = t + nw < n_tiles;   // wave-uniform
+    if (more) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) acc ^= v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+      for (int u = 0; u < U; ++u) nxt[u] = __builtin_nontemporal_load(p + (t + nw) * (U * 64) + lane + u * 64);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc ^= cur[u].x ^ cur[u].y ^ cur[u].z ^ cur[u].w;
+    if (more) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+    }
   }
   if (acc == 0x9E3779B9u) *sink = acc;   // keeps the loads alive; practically never true
 }
@@ -40,13 +53,24 @@ __global__ __launch_bounds__(256) void probe_read_ranges_kernel(const v4u_t* __r
   const size_t lane = threadIdx.x & 63;
   const ProbeRange r = rg[blockIdx.x];
   unsigned acc = 0;
-  for (long long t = r.t_begin + r.wid0 + (threadIdx.x >> 6); t < r.t_end; t += r.nwv) {
-    const v4u_t* q = p + (size_t)t * (U * 64) + lane;
-    v4u_t v[U];
+  v4u_t cur[U], nxt[U];
+  long long t = r.t_begin + r.wid0 + (threadIdx.x >> 6);
+  if (t < r.t_end) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(q + u * 64);
+    for (int u = 0; u < U; ++u) cur[u] = __builtin_nontemporal_load(p + (size_t)t * (U * 64) + lane + u * 64);
+  }
+  for (; t < r.t_end; t += r.nwv) {
+    const bool more = t + r.nwv < r.t_end;
+    if (more) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) acc ^= v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+      for (int u = 0; u < U; ++u) nxt[u] = __builtin_nontemporal_load(p + (size_t)(t + r.nwv) * (U * 64) + lane + u * 64);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc ^= cur[u].x ^ cur[u].y ^ cur[u].z ^ cur[u].w;
+    if (more) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+    }
   }
   if (acc == 0x9E3779B9u) *sink = acc;
 }

@@ -224,6 +224,35 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __rest
   }
 }
 
+// The queries of a batched (MFMA-path) search in ONE launch: rows < b are normalised exactly as normalize_rows_kernel does
+// (fp32 copy for the rerank + its bf16 rounding for the pass kernels), rows [b, b_pad) of the bf16 image are zero, and
+// the batch's overflow flag is cleared — normalize_rows_kernel + queries_to_bf16_kernel were two launches and a gap
+// (~10 us of a 0.37 ms step at an 8-GPU shard's size).
+__global__ __launch_bounds__(256) void prep_queries_bf16_kernel(const float* __restrict__ in, int dim, int b, int b_pad,
+                                                                float* __restrict__ out_f32, uint16_t* __restrict__ out_bf16,
+                                                                int* __restrict__ clear_flag) {
+  if (clear_flag && blockIdx.x == 0 && threadIdx.x == 0) *clear_flag = 0;
+  const int lane = lane_id();
+  const int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int nw = gridDim.x * (blockDim.x >> 6);
+  for (int r = w; r < b_pad; r += nw) {
+    if (r >= b) {   // wave-uniform
+      for (int c = lane; c < dim; c += 64) out_bf16[(size_t)r * dim + c] = 0;
+      continue;
+    }
+    const float* x = in + (size_t)r * dim;
+    double ss = 0.0;
+    for (int c = lane; c < dim; c += 64) { const double v = (double)x[c]; ss = fma(v, v, ss); }
+    ss = wave_sum_f64(ss);
+    const double inv = 1.0 / (sqrt(ss) + 1e-30);
+    for (int c = lane; c < dim; c += 64) {
+      const float y = (float)((double)x[c] * inv);
+      out_f32[(size_t)r * dim + c] = y;
+      out_bf16[(size_t)r * dim + c] = f32_to_bf16_rne(y);
+    }
+  }
+}
+
 // The same for the add path's common case (dim a multiple of 4, <= 2048, 16-byte aligned input rows): a wave brings its
 // whole row into registers with NV float4 loads per lane (all in flight together), squares and sums in fp64 as above, and
 // writes float4 / 4 x bf16 per lane.  One read of the input instead of two, 16-byte accesses instead of 4- and 2-byte

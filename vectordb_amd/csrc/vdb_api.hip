@@ -105,6 +105,7 @@ struct vdb {
                                  // 650 is as fast but fills the sample pass's candidate buffers to half their capacity)
   int mfma_variant = 6;          // 4 = 128-wide query tiles only; 5 = + the 256-wide tile (both scan_mfma6.h)
                                  // where it pads the batch <= 1.5x further; 6 = + the streaming kernel (scan_stream.h) for <= 64 queries
+  const float* qb16_for_qn = nullptr; int qb16_for_b = 0;   // prep_queries_mfma left the bf16 image of exactly these queries in w_mfma
   int mfma_last_b = 0;           // batch size of the last MFMA search (locates its overflow flag)
   int mfma_last_skipped = 0;     // tiles the last MFMA search's final pass left out (the sample pass's)
   int mfma_force_fallback = 0;   // test hook: route through the exact list kernel
@@ -344,6 +345,8 @@ int mfma_search(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
   a.one_pass_span = h->mfma_one_pass_span;
   a.skip_sample = h->mfma_skip_sample; a.force_fallback = h->mfma_force_fallback; a.ablate = h->mfma_ablate; a.stream_nt = h->stream_nt;
   a.qb16 = (unsigned char*)h->w_mfma.p;
+  a.qb16_ready = h->qb16_for_qn == qn && h->qb16_for_b == b;
+  h->qb16_for_qn = nullptr; h->qb16_for_b = 0;
   a.cand_s = (float*)h->w_cand_s.p; a.cand_i = (int*)h->w_cand_i.p; a.cand_cnt = (int*)h->w_cand_cnt.p;
   a.thr = (float*)h->w_thr.p; a.dense = (float*)h->w_dense.p;
   a.list_s = (float*)h->w_list_s.p; a.list_i = (int*)h->w_list_i.p;
@@ -589,6 +592,22 @@ int prep_queries(vdb_t* h, const float* q_dev, int b, hipStream_t st, float** qn
   return VDB_OK;
 }
 
+// The queries of a batch that will take the batched MFMA path as ONE chunk: fp32 normalised copy + bf16 image + cleared
+// overflow flag in one launch (mfma_search then skips its own conversion).
+int prep_queries_mfma(vdb_t* h, const float* q_dev, int b, hipStream_t st, float** qn) {
+  const MfPlan pl = mfma_plan(b, (int)h->n, h->n_cu, h->mfma_variant);
+  int rc;
+  if ((rc = ensure(h, h->w_q, (size_t)b * h->ld * 4))) return rc;
+  if ((rc = ensure(h, h->w_mfma, (size_t)pl.b_pad * kMfRowBytesC))) return rc;
+  if ((rc = ensure(h, h->w_cand_cnt, ((size_t)b * kMfCntStrideC + 16) * 4))) return rc;
+  hipLaunchKernelGGL(prep_queries_bf16_kernel, dim3(std::max(1, std::min((pl.b_pad + 3) / 4, h->n_cu * 8))), dim3(256), 0, st, q_dev, h->dim, b, pl.b_pad,
+                     (float*)h->w_q.p, (uint16_t*)h->w_mfma.p, (int*)h->w_cand_cnt.p + (size_t)b * kMfCntStrideC);
+  HIP_TRY(h, hipGetLastError());
+  *qn = (float*)h->w_q.p;
+  h->qb16_for_qn = *qn; h->qb16_for_b = b;
+  return VDB_OK;
+}
+
 // The queries search_core gets: normalised into the workspace, or — where the fused kernel will serve the batch and
 // normalises in its own prologue — the caller's raw ones as they are.
 bool will_fuse(vdb_t* h, int b, int k, int kp, bool masked) {
@@ -599,7 +618,8 @@ int prep_or_pass(vdb_t* h, const float* q_dev, int b, int k, int kp, bool masked
   *raw = will_fuse(h, b, k, kp, masked);
   if (*raw) { *q_out = q_dev; return VDB_OK; }
   float* qn = nullptr;
-  const int rc = prep_queries(h, q_dev, b, st, &qn);
+  const bool one_mfma_chunk = b <= kMfMaxQueriesPerCall && h->n > 0 && takes_mfma_path(h, b, kp ? kp : k, kp, masked);
+  const int rc = one_mfma_chunk ? prep_queries_mfma(h, q_dev, b, st, &qn) : prep_queries(h, q_dev, b, st, &qn);
   *q_out = qn;
   return rc;
 }
@@ -1832,7 +1852,9 @@ int vdb_get_stat(vdb_t* h, const char* name, int64_t* value) {
     // read probe: the scan's own launch shape — 12 KiB contiguous per wave and step, non-temporal, 256 threads,
     // 2 or 4 blocks per CU (the scan runs 2) — best of 4 timed launches each after a warm-up launch
     const size_t n16 = bytes / 16 / (12 * 64) * (12 * 64);   // whole 12 KiB tiles
-    for (int rep = 0; rep < (rd ? 9 : 4); ++rep) {
+    // (the read probe runs ~60 ms in all: after the idle moment a caller's synchronisation leaves, the first launches of a
+    // burst stream a few per cent under the rate a continuous loop of scans settles at)
+    for (int rep = 0; rep < (rd ? 25 : 4); ++rep) {
       HIP_TRY(h, hipEventRecord(e0, h->stream));
       const int gm = (rep & 1) ? 2 : 4;
       if (rd) hipLaunchKernelGGL((probe_read_kernel<12>), dim3(h->n_cu * gm), dim3(256), 0, h->stream, (const v4u_t*)src, n16, (unsigned*)h->w_thr.p);
@@ -1871,7 +1893,7 @@ int vdb_get_stat(vdb_t* h, const char* name, int64_t* value) {
       }
       if ((rc = ensure(h, h->w_idx, rg.size() * sizeof(ProbeRange)))) return rc;
       HIP_TRY(h, hipMemcpy(h->w_idx.p, rg.data(), rg.size() * sizeof(ProbeRange), hipMemcpyHostToDevice));
-      for (int rep = 0; rep < 5; ++rep) {
+      for (int rep = 0; rep < 25; ++rep) {
         HIP_TRY(h, hipEventRecord(e0, h->stream));
         hipLaunchKernelGGL((probe_read_ranges_kernel<12>), dim3(n_blocks), dim3(256), 0, h->stream, (const v4u_t*)src, (const ProbeRange*)h->w_idx.p, (unsigned*)h->w_thr.p);
         HIP_TRY(h, hipGetLastError());
