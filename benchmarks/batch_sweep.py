@@ -62,7 +62,7 @@ def main():
             if b <= 64:
                 ix.set_option("batch_mfma_min_b", 1 << 20); r["gemv"] = timed(ix, q, b, k, kp, max(3, iters // 4)); ix.set_option("batch_mfma_min_b", 2)
                 ix.set_option("mfma_variant", 6); ix.set_option("stream_nt_loads", 0); r["stream"] = timed(ix, q, b, k, kp, iters)
-                ix.set_option("stream_nt_loads", 1); r["stream_nt"] = timed(ix, q, b, k, kp, iters); ix.set_option("stream_nt_loads", 0)
+                ix.set_option("stream_nt_loads", 1); r["stream_nt"] = timed(ix, q, b, k, kp, iters)   # (1 is the engine's default: it stays)
             if b >= 2:
                 ix.set_option("mfma_variant", 5); r["tiled"] = timed(ix, q, b, k, kp, iters)
             ix.set_option("mfma_variant", 6)

@@ -257,6 +257,7 @@ __global__ __launch_bounds__(256) void prep_queries_bf16_kernel(const float* __r
 // whole row into registers with NV float4 loads per lane (all in flight together), squares and sums in fp64 as above, and
 // writes float4 / 4 x bf16 per lane.  One read of the input instead of two, 16-byte accesses instead of 4- and 2-byte
 // ones: HBM-bound copy work (read 4, write 4 [+2] bytes per element).
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 template <int NV>
 __global__ __launch_bounds__(256) void normalize_rows_vec_kernel(const float* __restrict__ in, int in_ld, long long n,
                                                                  int dim, int ld, float* __restrict__ out_f32,
@@ -265,35 +266,47 @@ __global__ __launch_bounds__(256) void normalize_rows_vec_kernel(const float* __
   const long long w = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const long long nw = (long long)gridDim.x * (blockDim.x >> 6);
   const int nv_in = dim >> 2, nv_out = ld >> 2;
-  for (long long r = w; r < n; r += nw) {
-    const f32x4* x = reinterpret_cast<const f32x4*>(in + r * in_ld);
-    f32x4 v[NV];
+  // two rows per wave and step (round 3): their 2 x NV loads are in flight together, and the stores are non-temporal —
+  // the rows are not read again before the scan streams them, so they need not displace anything in L2
+  constexpr int RW = NV <= 4 ? 2 : 1;
+  for (long long r0 = w * RW; r0 < n; r0 += nw * RW) {
+    f32x4 v[RW][NV];
 #pragma unroll
-    for (int t = 0; t < NV; ++t) {
-      const int j = lane + 64 * t;
-      v[t] = j < nv_in ? __builtin_nontemporal_load(x + j) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int u = 0; u < RW; ++u) {
+      const long long r = r0 + u < n ? r0 + u : n - 1;   // (a clamped second row is loaded again, never stored)
+      const f32x4* x = reinterpret_cast<const f32x4*>(in + r * in_ld);
+#pragma unroll
+      for (int t = 0; t < NV; ++t) {
+        const int j = lane + 64 * t;
+        v[u][t] = j < nv_in ? __builtin_nontemporal_load(x + j) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
     }
-    double ss = 0.0;
 #pragma unroll
-    for (int t = 0; t < NV; ++t) {
-      ss += (double)v[t].x * (double)v[t].x; ss += (double)v[t].y * (double)v[t].y;
-      ss += (double)v[t].z * (double)v[t].z; ss += (double)v[t].w * (double)v[t].w;
-    }
-    ss = wave_sum_f64(ss);
-    const double inv = 1.0 / (sqrt(ss) + 1e-30);
+    for (int u = 0; u < RW; ++u) {
+      const long long r = r0 + u;
+      if (r >= n) break;   // wave-uniform
+      double ss = 0.0;
 #pragma unroll
-    for (int t = 0; t < NV; ++t) {
-      const int j = lane + 64 * t;
-      if (j < nv_out) {
-        f32x4 y;
-        y.x = (float)((double)v[t].x * inv); y.y = (float)((double)v[t].y * inv);
-        y.z = (float)((double)v[t].z * inv); y.w = (float)((double)v[t].w * inv);
-        if (out_f32) reinterpret_cast<f32x4*>(out_f32 + r * ld)[j] = y;
-        if (out_bf16) {
-          uint2 p;
-          p.x = (uint32_t)f32_to_bf16_rne(y.x) | ((uint32_t)f32_to_bf16_rne(y.y) << 16);
-          p.y = (uint32_t)f32_to_bf16_rne(y.z) | ((uint32_t)f32_to_bf16_rne(y.w) << 16);
-          reinterpret_cast<uint2*>(out_bf16 + r * ld)[j] = p;
+      for (int t = 0; t < NV; ++t) {
+        ss += (double)v[u][t].x * (double)v[u][t].x; ss += (double)v[u][t].y * (double)v[u][t].y;
+        ss += (double)v[u][t].z * (double)v[u][t].z; ss += (double)v[u][t].w * (double)v[u][t].w;
+      }
+      ss = wave_sum_f64(ss);
+      const double inv = 1.0 / (sqrt(ss) + 1e-30);
+#pragma unroll
+      for (int t = 0; t < NV; ++t) {
+        const int j = lane + 64 * t;
+        if (j < nv_out) {
+          f32x4 y;
+          y.x = (float)((double)v[u][t].x * inv); y.y = (float)((double)v[u][t].y * inv);
+          y.z = (float)((double)v[u][t].z * inv); y.w = (float)((double)v[u][t].w * inv);
+          if (out_f32) __builtin_nontemporal_store(y, reinterpret_cast<f32x4*>(out_f32 + r * ld) + j);
+          if (out_bf16) {
+            u32x2 p;
+            p.x = (uint32_t)f32_to_bf16_rne(y.x) | ((uint32_t)f32_to_bf16_rne(y.y) << 16);
+            p.y = (uint32_t)f32_to_bf16_rne(y.z) | ((uint32_t)f32_to_bf16_rne(y.w) << 16);
+            __builtin_nontemporal_store(p, reinterpret_cast<u32x2*>(out_bf16 + r * ld) + j);
+          }
         }
       }
     }

@@ -372,21 +372,25 @@ int mfma_search(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
   return VDB_OK;
 }
 
-// Which path serves a bf16 768-d batch faster?  Coefficients measured on MI355X (10M and 1M rows, round 2):
-// a GEMV pass costs a launch (~12 us) plus the corpus at ~6.95 TB/s, times 1.0 / 1.06 / 1.64 for 1 / 2 / 4
-// queries per pass (b = 3 runs as 2 + 1).  The batched path costs ~95 us of launches (dense sample, selects,
-// append passes) plus, per row: the streaming kernel (<= 64 queries) the corpus at ~6.65 TB/s (whole lines through
-// its LDS ring; 6.0 in the register form); the tiled kernels 0.25 ns per 128-query tile or 0.36 (+0.05) ns per
-// 256-query tile.
-// Measured at 10M rows: b = 2 GEMV 2.34 ms vs streaming 2.41; b = 4 3.70 vs 2.41; b = 64 58.6 vs 2.45-2.50;
-// b = 65 tiled 3.03; b = 128 3.25.
+// Which path serves a bf16 768-d batch faster?  Coefficients measured on MI355X, refitted in round 3 to the sweeps at 10M and
+// 1.25M rows (profiles/r03_batch_sweep.txt: fixed cost + bytes / rate per search, timing events on every call):
+//   one query on the fused scan       56 us + bytes / 7.33 TB/s   (2.161 / 0.328 ms)
+//   two queries in one fused pass    100 us + bytes / 7.11 TB/s   (2.271 / 0.381 ms: the second query's fold and the fenced
+//                                                                  list stores are a fixed cost, not a rate)
+//   four queries in one pass          1.64 x a one-query pass (round 2; b = 3 runs as 2 + 1)
+//   streaming kernel (<= 64 queries)  80 us + bytes / 7.04 TB/s   (2.272 / 0.362 ms: whole lines through its LDS ring,
+//                                                                  dense sample, bound, two selections, finish)
+//   tiled kernels                     100 us + 0.25 ns per row and 128-query tile, or 0.36 (+0.05) ns per row and 256-query tile
+// So two queries take the streaming kernel below ~8M rows (0.362 vs 0.381 ms at 1.25M) and the scan above, three and
+// more the batched path wherever it is allowed.
 bool mfma_is_faster(int b, int n_rows, int variant_opt) {
-  const double pass = 12e-6 + (double)n_rows * kMfRowBytesC / 6.95e12;
+  const double bytes = (double)n_rows * kMfRowBytesC;
+  const double pass1 = 56e-6 + bytes / 7.33e12, pass2 = 100e-6 + bytes / 7.11e12;
   const int r = b & 3;
-  const double gemv = pass * (1.64 * (b >> 2) + (r == 3 ? 2.06 : r == 2 ? 1.06 : r == 1 ? 1.0 : 0.0));
+  const double gemv = 1.64 * pass1 * (b >> 2) + (r == 3 ? pass2 + pass1 : r == 2 ? pass2 : r == 1 ? pass1 : 0.0);
   const MfPlan pl = mfma_plan(b, n_rows, 256, variant_opt);
   double mfma;
-  if (pl.variant == 6) mfma = 95e-6 + (double)n_rows * kMfRowBytesC / 6.65e12;
+  if (pl.variant == 6) mfma = 80e-6 + bytes / 7.04e12;
   else if (pl.variant == 5) mfma = 100e-6 + (double)n_rows * (0.36e-9 * pl.n_qt + 0.05e-9);
   else mfma = 100e-6 + (double)n_rows * 0.25e-9 * pl.n_qt;
   return mfma < gemv;
