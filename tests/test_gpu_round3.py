@@ -17,7 +17,7 @@ def _qn(oracle_mod, queries):
 def _fused_vs_unfused(ix, queries, k, kp, what, allow=None):
     """The same search through the fused kernel and through normalise + scan + fold + finish: identical bits."""
     out = []
-    for fuse in (1, 0, 1):      # the third call re-uses the arrival counter the first one reset
+    for fuse in (2, 0, 2):      # 2 = fused wherever the shape allows (1, the default, fuses 2..4 queries on large stores only); the third call re-uses the arrival counter the first one reset
         ix.set_option("fuse_small_batch", fuse)
         out.append(ix.search(queries, k, kp) if allow is None else ix.search_masked(queries, k, allow, kp))
     ix.set_option("fuse_small_batch", 1)
@@ -128,6 +128,8 @@ def test_fused_search_on_device_pointers_and_a_sharded_handle(hip_lib, oracle_mo
     sh = FlatIndex(dim, "bf16", True, devices=[0, 0, 0])
     sh.reserve(n)
     sh.add_synth(0, n, spec)
+    one.set_option("fuse_small_batch", 2)       # two and four queries in one launch too (the default fuses them on large stores only)
+    sh.set_option("fuse_small_batch", 2)
     st = torch.cuda.current_stream().cuda_stream
     q_t = torch.from_numpy(queries).cuda()
     for b in (1, 2, 4):

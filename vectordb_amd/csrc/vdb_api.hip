@@ -110,7 +110,7 @@ struct vdb {
   int mfma_last_skipped = 0;     // tiles the last MFMA search's final pass left out (the sample pass's)
   int mfma_force_fallback = 0;   // test hook: route through the exact list kernel
   int scan_balance = 1;          // the fused kernel deals its tiles out by self-tuning per-XCD shares (XCDs stream at different rates)
-  int fuse_small = 1;            // <= 4 queries with k' <= 64 on the fast dims: normalise + scan + fold + rerank in ONE launch (scan_fused.h)
+  int fuse_small = 1;            // <= 4 queries with k' <= 64 on the fast dims: normalise + scan + fold + rerank in ONE launch (scan_fused.h); see fuses()
   DevBuf w_stamps;               // diagnostic: clock stamps of the fused kernel (option "scan_stamps")
   DevBuf w_ticket;               // the fused kernel's arrival counter: zeroed at create, reset by the kernel's last block
   void* na_scratch = nullptr;    // this device's copy of `scratch` (hipGetSymbolAddress at create)
@@ -462,8 +462,13 @@ bool takes_mfma_path(vdb_t* h, int b, int kk, int kp, bool masked) {
 }
 
 // Is this GEMV-path batch served by the fused kernel (scan_fused.h: one launch per <= 4 queries)?
+// One query: always (one launch instead of four).  Two to four queries in a pass: the last block folds, re-scores and
+// ranks them ONE AFTER THE OTHER (~20 us each) while the rest of the chip idles, which the four-launch form does for all
+// queries at once — the fused form wins only where the scan is long (interleaved A/B, profiles/r03_fused_vs_unfused_ab.txt:
+// 4 queries 0.104 vs 0.056 ms at 14 777 rows, 0.599 vs 0.572 at 1.25M, 3.60 vs 3.75 at 10M).  fuse_small_batch = 2 forces it.
 bool fuses(vdb_t* h, int b, int kk) {
-  return h->fuse_small && b <= 4 && kk <= 64 && fast_dim(h) && gemv_grid(h) <= kFusedMaxParts;
+  if (!h->fuse_small || b > 4 || kk > 64 || !fast_dim(h) || gemv_grid(h) > kFusedMaxParts) return false;
+  return h->fuse_small >= 2 || b == 1 || (b != 3 && h->n >= 4000000);
 }
 
 // The fused launches of b <= 4 queries (4, 2 or 1 per corpus pass): q are raw queries (q_raw: the kernel normalises
@@ -1773,7 +1778,7 @@ int vdb_set_option(vdb_t* h, const char* name, int64_t value) {
     h->mfma_append_cap = (int)value; return VDB_OK;
   }
   if (!strcmp(name, "mfma_cost_model")) { h->mfma_cost_model = value != 0; return VDB_OK; }
-  if (!strcmp(name, "fuse_small_batch")) { h->fuse_small = value != 0; return VDB_OK; }
+  if (!strcmp(name, "fuse_small_batch")) { h->fuse_small = (int)std::max<int64_t>(0, std::min<int64_t>(value, 2)); return VDB_OK; }   // 0 never, 1 where it wins, 2 wherever the shape allows
   if (!strcmp(name, "scan_balance")) { h->scan_balance = (int)std::max<int64_t>(0, std::min<int64_t>(value, 2)); return VDB_OK; }   // 0: every wave of the grid takes every nw-th tile
   if (!strcmp(name, "scan_stamps")) {   // diagnostic: the fused kernel writes clock stamps (read back with get_stat "scan_stamp_<i>")
     int rc = set_device(h);
