@@ -344,7 +344,26 @@ __global__ __launch_bounds__(kScanThreads) void scan_topk_fused_kernel(const Fus
       __syncthreads();
     }
     if (q == 0) stamp(5);
-    rank_and_write(t.ls, t.li, kk, a.k, a.row_offset, a.out_idx + (size_t)q * a.k, a.out_dist + (size_t)q * a.k);
+    // rank by (distance, row) and write: wave 0 alone, one list entry per lane (k' <= 64).  rank_and_write's form — pad
+    // everything, barrier, overwrite — waits for the padding stores at the barrier (~1.5 us); here every output place
+    // is written exactly once and no barrier stands between the ranking and the stores.  Same ranks, same bits.
+    if (w == 0) {
+      const int id = lane < kk ? t.li[lane] : kIdxSentinel;
+      const float sc = lane < kk ? t.ls[lane] : 0.f;
+      const bool ok = id != kIdxSentinel && sc == sc;
+      const float d = 1.0f - sc;
+      int rank = 0;
+      for (int j = 0; j < kk; ++j) {
+        const int oj = t.li[j];
+        const float sj = t.ls[j];
+        rank += (oj != kIdxSentinel && sj == sj && dist_better(1.0f - sj, oj, d, id)) ? 1 : 0;
+      }
+      const int n_ok = __builtin_popcountll(__ballot(ok));
+      long long* oi = a.out_idx + (size_t)q * a.k;
+      float* od = a.out_dist + (size_t)q * a.k;
+      if (ok && rank < a.k) { oi[rank] = (long long)id + a.row_offset; od[rank] = d; }
+      for (int p = n_ok + lane; p < a.k; p += 64) { oi[p] = -1; od[p] = INFINITY; }   // fewer than k candidates: padding behind them
+    }
     __syncthreads();
     if (q == 0) stamp(6);
   }

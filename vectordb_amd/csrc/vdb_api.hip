@@ -118,6 +118,7 @@ struct vdb {
   // dim/ld/dtype/keep_f32/device(= shard 0's)/stream/pin/w_stage/w_out_i/w_gather are used on it
   std::vector<vdb*> shards;
   std::vector<hipEvent_t> shard_done;   // per shard: its result is in the gather buffer
+  std::vector<hipEvent_t> shard_aux;    // per shard, created on ITS device (an event is recorded on streams of its own device only): the self-join's "queries ready"
   std::vector<char> shard_direct;       // per shard: its finish kernel stores straight into shard 0's memory (same device or P2P)
   int shard_force_remote = 0;           // test hook: every shard but the first takes the no-peer-access path (query and result peer copies)
   int shard_serial_streams = 0;         // diagnostic: shard 0 on its own stream like the others (the round-2 form)
@@ -311,7 +312,7 @@ int finish_search(vdb_t* h, const WsPtrs& W, int b, int n_parts, int kk, int k, 
 // full pass -> exact top-k' lists; exact list kernel as the device-flagged overflow fallback; then the shared
 // fp32 finish.  At most kMfMaxQueriesPerCall queries per call: the candidate buffers are b x cap x 8 bytes.
 int mfma_search(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_row0, int64_t* out_idx,
-                float* out_dist, hipStream_t st, bool last_chunk) {
+                float* out_dist, hipStream_t st, bool last_chunk, bool qb16_ready) {
   const int kk = kp ? kp : k;
   const int n_rows = (int)h->n;
   const MfPlan pl = mfma_plan(b, n_rows, h->n_cu, h->mfma_variant);
@@ -345,8 +346,7 @@ int mfma_search(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
   a.one_pass_span = h->mfma_one_pass_span;
   a.skip_sample = h->mfma_skip_sample; a.force_fallback = h->mfma_force_fallback; a.ablate = h->mfma_ablate; a.stream_nt = h->stream_nt;
   a.qb16 = (unsigned char*)h->w_mfma.p;
-  a.qb16_ready = h->qb16_for_qn == qn && h->qb16_for_b == b;
-  h->qb16_for_qn = nullptr; h->qb16_for_b = 0;
+  a.qb16_ready = qb16_ready;
   a.cand_s = (float*)h->w_cand_s.p; a.cand_i = (int*)h->w_cand_i.p; a.cand_cnt = (int*)h->w_cand_cnt.p;
   a.thr = (float*)h->w_thr.p; a.dense = (float*)h->w_dense.p;
   a.list_s = (float*)h->w_list_s.p; a.list_i = (int*)h->w_list_i.p;
@@ -506,6 +506,9 @@ int search_core(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
                 float* out_dist, hipStream_t st, const unsigned* allow = nullptr, bool q_raw = false) {
   const int kk = kp ? kp : k;
   const int n_rows = (int)h->n;
+  // prep_queries_mfma's note "the bf16 image of exactly these queries is in place" is good for THIS search only
+  const bool qb16_ready = h->qb16_for_qn == qn && h->qb16_for_b == b;
+  h->qb16_for_qn = nullptr; h->qb16_for_b = 0;
   // slot 0 of the two-phase search shares these workspaces: a scan pending there would be overwritten
   if (h->split[0].pending || h->split[1].pending)
     return fail(h, VDB_ERR_STATE, "search: a two-phase scan is pending on this handle (call vdb_search_finish_dev first)");
@@ -538,7 +541,7 @@ int search_core(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
     for (int q0 = 0; q0 < b; q0 += kMfMaxQueriesPerCall) {
       const int cb = std::min(kMfMaxQueriesPerCall, b - q0);
       if ((rc = mfma_search(h, qn + (size_t)q0 * h->ld, cb, k, kp, self_row0 >= 0 ? self_row0 + q0 : -1, out_idx + (size_t)q0 * k,
-                            out_dist + (size_t)q0 * k, st, q0 + cb == b))) return rc;
+                            out_dist + (size_t)q0 * k, st, q0 + cb == b, qb16_ready && cb == b))) return rc;
     }
     if (h->ev_on) { HIP_TRY(h, hipEventRecord(h->ev[2], st)); h->timing_valid = true; }
     return VDB_OK;
@@ -704,10 +707,12 @@ int vdb_create_sharded(vdb_t** out, int dim, int dtype, int keep_f32, const int*
       hipEventCreateWithFlags(&p->ev_q, hipEventDisableTiming) != hipSuccess)
     return bail(VDB_ERR_DEVICE, "vdb_create_sharded: stream/event creation failed");
   p->shard_done.assign(n_devices, nullptr);
+  p->shard_aux.assign(n_devices, nullptr);
   p->shard_direct.assign(n_devices, 0);
   for (int s = 0; s < n_devices; ++s) {
     vdb_t* c = p->shards[s];
-    if (hipSetDevice(c->device) != hipSuccess || hipEventCreateWithFlags(&p->shard_done[s], hipEventDisableTiming) != hipSuccess)
+    if (hipSetDevice(c->device) != hipSuccess || hipEventCreateWithFlags(&p->shard_done[s], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&p->shard_aux[s], hipEventDisableTiming) != hipSuccess)
       return bail(VDB_ERR_DEVICE, "vdb_create_sharded: event creation failed");
     if (c->device == p->device) { p->shard_direct[s] = 1; continue; }
     // P2P: the shard's finish kernel stores its k results straight into shard 0's gather buffer over xGMI
@@ -726,6 +731,7 @@ void vdb_destroy(vdb_t* h) {
   if (!h) return;
   for (vdb_t* c : h->shards) vdb_destroy(c);
   for (size_t s = 0; s < h->shard_done.size(); ++s) if (h->shard_done[s]) (void)hipEventDestroy(h->shard_done[s]);
+  for (size_t s = 0; s < h->shard_aux.size(); ++s) if (h->shard_aux[s]) (void)hipEventDestroy(h->shard_aux[s]);
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
@@ -1353,10 +1359,9 @@ int sharded_selfjoin(vdb_t* h, int64_t q_row0, int64_t q_n, int k, int exclude_s
     HIP_TRY(h, hipHostMalloc(&h->pin, 2 * obytes, hipHostMallocDefault));
     h->pin_bytes = 2 * obytes;
   }
-  hipEvent_t copied[2] = {nullptr, nullptr}, q_ready = nullptr;
-  auto cleanup = [&]() { for (hipEvent_t e : copied) if (e) (void)hipEventDestroy(e); if (q_ready) (void)hipEventDestroy(q_ready); };
-  if (hipEventCreateWithFlags(&copied[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&copied[1], hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&q_ready, hipEventDisableTiming) != hipSuccess) {
+  hipEvent_t copied[2] = {nullptr, nullptr};   // (created with shard 0's device current: they are recorded on h->stream only)
+  auto cleanup = [&]() { for (hipEvent_t e : copied) if (e) (void)hipEventDestroy(e); };
+  if (hipEventCreateWithFlags(&copied[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&copied[1], hipEventDisableTiming) != hipSuccess) {
     cleanup();
     return fail(h, VDB_ERR_DEVICE, "selfjoin: event creation failed");
   }
@@ -1386,6 +1391,7 @@ int sharded_selfjoin(vdb_t* h, int64_t q_row0, int64_t q_n, int k, int exclude_s
       HIP_TRY(h, hipGetLastError());
       if (o->device != h->device) HIP_TRY(h, hipMemcpyPeerAsync(h->w_q.p, h->device, o->w_q1.p, o->device, (size_t)cb * h->ld * 4, o->stream));
       else HIP_TRY(h, hipMemcpyAsync(h->w_q.p, o->w_q1.p, (size_t)cb * h->ld * 4, hipMemcpyDeviceToDevice, o->stream));
+      hipEvent_t q_ready = h->shard_aux[(size_t)sp.s];   // the owner's own event: recorded on the owner's stream
       HIP_TRY(h, hipEventRecord(q_ready, o->stream));
       if ((r2 = set_device(h))) return r2;
       HIP_TRY(h, hipStreamWaitEvent(h->stream, q_ready, 0));
