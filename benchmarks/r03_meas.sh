@@ -2,7 +2,7 @@
 # Round-3 measurement set (one MI355X box): everything lands under gpurun_out/r03f/.  Each GPU step has its own time limit
 # and the steps are chained: a failure ends the script.
 set -e
-O=gpurun_out/r03n
+O=gpurun_out/r03u
 mkdir -p $O
 export TMPDIR=/tmp
 timeout -k 10 200 python bench.py > $O/bench.json 2> $O/bench.err
