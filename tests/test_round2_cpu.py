@@ -248,3 +248,27 @@ def test_collection_with_devices_on_the_oracle_twin(oracle_lib, tmp_path):
     ix.warm(8, 5)
     ix.rebalance(10)
     assert ix.count() == 703
+
+
+def test_bench_two_ranks_self_launch_reaches_the_gpu_check_and_a_failing_inproc_child_is_an_error_string():
+    """Round 3: `bench.py --gpus 2 --device-map 0,0 --backend gloo` (the diagnostic two-ranks-on-one-GPU form) passes the
+    node's GPU-count check, starts its ranks through torch.distributed.run and — on this GPU-less container — each rank
+    stops at "needs a GPU"; and the one-process sharded block, which runs in a child process, comes back as an error
+    string when that child fails instead of taking the JSON line down with it."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--device-map", "0,0", "--backend", "gloo", "--rows", "1000",
+                        "--steps", "1", "--warmup", "0", "--no-traffic-pass", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode != 0 and "bench.py needs a GPU" in (p.stderr + p.stdout) and "this node shows" not in (p.stderr + p.stdout)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    old_argv = sys.argv
+    sys.argv = ["bench.py", "--gpus", "2", "--rows", "1000", "--steps", "1", "--warmup", "0"]
+    try:
+        args = bench.parse_args()
+    finally:
+        sys.argv = old_argv
+    assert bench.device_map(args) == [] and args.backend == "nccl"
+    blk = bench.run_inproc_child(args, 2)
+    assert set(blk) == {"error"} and "exited with" in blk["error"]
