@@ -300,7 +300,35 @@ def inproc_child(args):
         last = (min(steps, 100) - 1) % n_sets
         idx_h, dist_h = oi[(min(steps, 100) - 1) & 3].cpu().numpy(), od[(min(steps, 100) - 1) & 3].cpu().numpy()
         src = np.array([query_source_row(qspec, last * b + j) for j in range(min(b, 8))])
+        rccl_blk = None
+        if len(set(devices)) == len(devices):
+            # the same steps with the exchange north_star names — ONE RCCL all-gather + merge — behind the same handle
+            try:
+                ix.set_option("shard_exchange_rccl", 1)
+                for i in range(20 + args.warmup):
+                    step(i)
+                torch.cuda.synchronize(dev)
+                t2 = time.perf_counter()
+                for i in range(steps):
+                    step(i)
+                torch.cuda.synchronize(dev)
+                e2 = time.perf_counter() - t2
+                lat2 = []
+                for i in range(min(steps, 100)):
+                    t3 = time.perf_counter()
+                    step(i)
+                    torch.cuda.synchronize(dev)
+                    lat2.append((time.perf_counter() - t3) * 1e3)
+                rccl_blk = {"ms_per_step": 1e3 * e2 / steps, "value": steps * b / e2, "sync_latency_ms_median": float(np.median(lat2))}
+            except Exception as exc:          # noqa: BLE001 — a diagnostic block must not take the line down
+                rccl_blk = {"error": str(exc)[:300]}
+            finally:
+                try:
+                    ix.set_option("shard_exchange_rccl", 0)
+                except Exception:             # noqa: BLE001
+                    pass
         out[label] = {"value": steps * b / elapsed, "unit": "queries/s", "ms_per_step": 1e3 * elapsed / steps, "steps": steps,
+                      "with_rccl_all_gather_exchange": rccl_blk,
                       "host_issue_ms_per_step": 1e3 * t_host / steps, "library_host_us_per_call": issue_us,
                       "sync_latency_ms": {"median": float(np.median(lat)), "p99": float(np.sort(lat)[min(len(lat) - 1, int(0.99 * len(lat)))])},
                       "planted_neighbour_first_and_ascending": bool(np.array_equal(idx_h[: len(src), 0], src)) and bool(np.all(np.diff(dist_h, axis=1) >= 0))}

@@ -281,6 +281,14 @@ int vdb_timing_stats(vdb_t* h, int64_t* n_searches, double* scan_ms_sum, double*
  * best; or 100..900), "mfma_skip_sample" (default 1: the last of two append passes leaves out the tiles the sample pass
  * multiplied), "mfma_force_fallback" (test hook: the exact list kernel serves the batch), "mfma_ablate" (diagnostic builds of the
  * pass kernels; bits 1, 2, 4, 8 give INVALID results — timing only; bit 128 = one append flush per hit).
+ * Round 3: "fuse_small_batch" (0: never the one-launch search; 1, default: where it wins — one query always, two or four
+ * from 4M rows on; 2: wherever the shape allows), "mfma_dense_tiles" (256-row tiles of the dense sample that gives the first
+ * threshold; 0, default: 64, or 128 from 6M rows on), "mfma_one_pass_span" (default 24: stores up to that many times the
+ * dense sample are searched in one append pass).  On a sharded handle only: "shard_exchange_rccl" (1: the shards' k results
+ * are exchanged by ONE RCCL all-gather — loaded on demand, one rank per GPU, VDB_ERR_STATE when two shards share a device —
+ * and merged on shard 0, the exchange SURVEY 8e names; 0, default: P2P stores into shard 0's gather buffer),
+ * "shard_force_remote" (test hook: every shard but the first takes the no-peer-access path), "shard_own_stream_for_shard0"
+ * (diagnostic: the round-2 form).
  * Unknown names return VDB_ERR_ARG. */
 int vdb_set_option(vdb_t* h, const char* name, int64_t value);
 

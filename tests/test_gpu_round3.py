@@ -313,3 +313,31 @@ def test_collection_on_a_sharded_segment(hip_lib, oracle_mod, tmp_path):
     again.add(embeddings=raw[:10] * 2.0, ids=[f"more_{i}" for i in range(10)])     # grows past the reopened partition
     assert again.count() == n + 10 and again.query(query_embeddings=[raw[3].tolist()], n_results=2)["ids"][0] == ["item_3", "more_3"]
     cols["one"][0].close()
+
+
+def test_rccl_exchange_behind_the_c_abi(hip_lib, oracle_mod):
+    """Option shard_exchange_rccl: the shards' results are exchanged by ONE RCCL all-gather (loaded on demand) and merged
+    on shard 0 — the exchange north_star names — instead of the P2P stores.  One rank per GPU, so on the one-GPU box it
+    runs with a single shard (the collective degenerates to a copy; the packed layout, the strides of the merge and the
+    on-demand loading are what is exercised), and a handle with two shards on one device refuses it.  tests/test_zy_physical_gpus.py
+    compares the two exchanges over the physical GPUs of a box that has several."""
+    from vectordb_amd._capi import VdbError
+    dim, n = 768, 30_000
+    spec = SynthSpec(seed=95, kind=1, n_clusters=173, noise=0.3)
+    queries = oracle_mod.synth_rows(0, 70, dim, SynthSpec(seed=96, kind=2, noise=0.5, base_kind=1, base_seed=95, base_n=n, base_n_clusters=173, base_noise=0.3))
+    one, sh = _pair(dim, "bf16", 1, n, spec)
+    assert sh.get_stat("shard_exchange_rccl") == 0
+    sh.set_option("shard_exchange_rccl", 1)
+    assert sh.get_stat("shard_exchange_rccl") == 1
+    for b, k in ((1, 10), (1, 3), (4, 10), (33, 5), (70, 10)):          # odd b * k: the packed block is padded to 8 bytes
+        _same(sh.search(queries[:b], k, 40), one.search(queries[:b], k, 40), f"rccl exchange b={b} k={k}")
+    allow = np.arange(n) % 5 == 0
+    _same(sh.search_masked(queries[:3], 7, allow, 40), one.search_masked(queries[:3], 7, allow, 40), "rccl exchange, masked")
+    sh.set_option("shard_exchange_rccl", 0)
+    _same(sh.search(queries[:4], 10, 40), one.search(queries[:4], 10, 40), "back on the P2P exchange")
+    one.close(); sh.close()
+    two = FlatIndex(dim, "bf16", True, devices=[0, 0])
+    with pytest.raises(VdbError) as e:
+        two.set_option("shard_exchange_rccl", 1)
+    assert e.value.code == -5 and "one rank per GPU" in str(e.value)
+    two.close()

@@ -38,6 +38,10 @@ def test_two_physical_gpus_when_the_box_has_them(hip_lib, oracle_mod, tmp_path):
     assert np.array_equal(i1, i0) and np.array_equal(d1, d0) and np.array_equal(r1, r0)
     allow = np.arange(n) % 7 == 0
     _same(sh.search_masked(queries[:4], 10, allow, 40), one.search_masked(queries[:4], 10, allow, 40), "masked, physical GPUs")
+    sh.set_option("shard_exchange_rccl", 1)            # the same searches with ONE RCCL all-gather instead of the P2P stores
+    for b in (1, 4, 33):
+        _same(sh.search(queries[:b], 10, 40), one.search(queries[:b], 10, 40), f"{len(devs)} GPUs, RCCL exchange, b={b}")
+    sh.set_option("shard_exchange_rccl", 0)
     sh.save(str(tmp_path / "s"))
     back = FlatIndex.load(str(tmp_path / "s"), "bf16", True, devices=devs[::-1])
     _same(back.search(queries[:5], 10, 40), one.search(queries[:5], 10, 40), "reload, physical GPUs")

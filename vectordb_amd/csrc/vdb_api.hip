@@ -3,6 +3,7 @@
 // instantiated in k_gemv.hip), scan_stream.h / scan_mfma{,3,4,5}.h (batched bf16 path on MFMA; k_mfma.hip) and
 // select.h (merges, fp32 rerank, shard merge; here).  gfx950 only; no CPU fallback.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <errno.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -54,6 +55,42 @@ static __device__ __align__(256) unsigned char scratch[kNaScratchBytes];
 constexpr int kMaxDevices = 64;
 std::mutex g_scratch_mu;
 void* g_scratch_ptr[kMaxDevices] = {};   // per device: the address of ITS copy of `scratch`
+
+// ---- RCCL, loaded on demand (option "shard_exchange_rccl" of a sharded handle): the library does not link against it ----
+// The exchange north_star names — an all-gather of the shards' k results followed by the on-device merge — as an
+// alternative to the P2P stores, behind the same C ABI, so that the two can be compared on one handle.  The process'
+// already-loaded RCCL is used where there is one (PyTorch-ROCm brings its own), else librccl.so.1 from the ROCm tree.
+struct RcclApi {
+  void* lib = nullptr;
+  int (*CommInitAll)(void** comms, int ndev, const int* devlist) = nullptr;
+  int (*CommDestroy)(void* comm) = nullptr;
+  int (*AllGather)(const void* send, void* recv, size_t count, int datatype, void* comm, hipStream_t stream) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+RcclApi g_rccl;
+std::mutex g_rccl_mu;
+bool load_rccl(std::string* why) {
+  std::lock_guard<std::mutex> lk(g_rccl_mu);
+  if (g_rccl.lib) return true;
+  void* lib = nullptr;
+  for (const char* name : {"librccl.so", "librccl.so.1"}) if (!lib) lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+  for (const char* name : {"librccl.so.1", "librccl.so"}) if (!lib) lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+  if (!lib) { *why = std::string("RCCL is not loadable: ") + (dlerror() ? dlerror() : "librccl.so not found"); return false; }
+  RcclApi a;
+  a.lib = lib;
+  a.CommInitAll = (decltype(a.CommInitAll))dlsym(lib, "ncclCommInitAll");
+  a.CommDestroy = (decltype(a.CommDestroy))dlsym(lib, "ncclCommDestroy");
+  a.AllGather = (decltype(a.AllGather))dlsym(lib, "ncclAllGather");
+  a.GroupStart = (decltype(a.GroupStart))dlsym(lib, "ncclGroupStart");
+  a.GroupEnd = (decltype(a.GroupEnd))dlsym(lib, "ncclGroupEnd");
+  a.GetErrorString = (decltype(a.GetErrorString))dlsym(lib, "ncclGetErrorString");
+  if (!a.CommInitAll || !a.CommDestroy || !a.AllGather || !a.GroupStart || !a.GroupEnd) { *why = "RCCL: a collective entry point is missing from the loaded library"; return false; }
+  g_rccl = a;
+  return true;
+}
+std::string rccl_err(int rc) { return g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : ("ncclResult " + std::to_string(rc)); }
 
 }  // namespace
 
@@ -120,6 +157,8 @@ struct vdb {
   std::vector<hipEvent_t> shard_done;   // per shard: its result is in the gather buffer
   std::vector<hipEvent_t> shard_aux;    // per shard, created on ITS device (an event is recorded on streams of its own device only): the self-join's "queries ready"
   std::vector<char> shard_direct;       // per shard: its finish kernel stores straight into shard 0's memory (same device or P2P)
+  std::vector<void*> comms;             // one RCCL communicator per shard (option shard_exchange_rccl; empty = the P2P exchange)
+  DevBuf w_xchg;                        // per SHARD: the all-gather's receive buffer, g packed result blocks
   int shard_force_remote = 0;           // test hook: every shard but the first takes the no-peer-access path (query and result peer copies)
   int shard_serial_streams = 0;         // diagnostic: shard 0 on its own stream like the others (the round-2 form)
   hipEvent_t ev_q = nullptr;            // the queries are ready on the caller's stream
@@ -732,11 +771,12 @@ void vdb_destroy(vdb_t* h) {
   for (vdb_t* c : h->shards) vdb_destroy(c);
   for (size_t s = 0; s < h->shard_done.size(); ++s) if (h->shard_done[s]) (void)hipEventDestroy(h->shard_done[s]);
   for (size_t s = 0; s < h->shard_aux.size(); ++s) if (h->shard_aux[s]) (void)hipEventDestroy(h->shard_aux[s]);
+  for (void* c : h->comms) if (c && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c);
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
   if (h->ev_q) (void)hipEventDestroy(h->ev_q);
-  DevBuf* bufs[] = {&h->w_stamps, &h->w_ticket, &h->w_gather, &h->w_fb_s, &h->w_fb_i, &h->w_q1, &h->w_part_s1, &h->w_part_i1, &h->w_part2_s1, &h->w_part2_i1, &h->w_q, &h->w_part_s, &h->w_part_i, &h->w_part2_s, &h->w_part2_i, &h->w_stage, &h->w_out_i, &h->w_out_d, &h->w_idx, &h->w_mfma,
+  DevBuf* bufs[] = {&h->w_xchg, &h->w_stamps, &h->w_ticket, &h->w_gather, &h->w_fb_s, &h->w_fb_i, &h->w_q1, &h->w_part_s1, &h->w_part_i1, &h->w_part2_s1, &h->w_part2_i1, &h->w_q, &h->w_part_s, &h->w_part_i, &h->w_part2_s, &h->w_part2_i, &h->w_stage, &h->w_out_i, &h->w_out_d, &h->w_idx, &h->w_mfma,
                     &h->w_cand_s, &h->w_cand_i, &h->w_cand_cnt, &h->w_thr, &h->w_dense, &h->w_list_s, &h->w_list_i, &h->w_mask, &h->w_seed_s, &h->w_seed_i};
   for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
   if (h->pin) (void)hipHostFree(h->pin);
@@ -961,6 +1001,8 @@ int sharded_search_dev(vdb_t* h, const float* q_dev0, int b, int k, int kp, int6
   };
   auto tp = issue_clock.t0;
   const bool masked = x.allow_host || x.allow_dev0;
+  const bool rccl = !h->comms.empty();
+  const size_t xwords = bk + (bk + 1) / 2;   // 8-byte words of one shard's packed result block (the all-gather's unit)
   const size_t q_bytes = (size_t)b * (x.q_unit_ld ? h->ld : h->dim) * 4;
   HIP_TRY(h, hipEventRecord(h->ev_q, st));   // the queries are ready; the previous call's merge (earlier on st) has read the gather buffer
   lap(0, tp);
@@ -1000,21 +1042,46 @@ int sharded_search_dev(vdb_t* h, const float* q_dev0, int b, int k, int kp, int6
     if (x.self_global0 >= 0 && x.self_global0 >= c->row_offset && x.self_global0 < c->row_offset + c->n) self0 = x.self_global0 - c->row_offset;
     int64_t* oi = g_idx + (size_t)s * bk;
     float* od = g_dist + (size_t)s * bk;
-    const bool direct = h->shard_direct[(size_t)s] && !(h->shard_force_remote && s > 0);
+    const bool direct = !rccl && h->shard_direct[(size_t)s] && !(h->shard_force_remote && s > 0);
     if (!direct) {
-      if ((rc = ensure(c, c->w_out_i, bk * 12))) return fail(h, rc, c->err);
+      if ((rc = ensure(c, c->w_out_i, xwords * 8))) return fail(h, rc, c->err);   // packed [idx int64 x bk | dist fp32 x bk | pad to 8]
       oi = (int64_t*)c->w_out_i.p;
       od = (float*)((char*)c->w_out_i.p + bk * 8);
+      if (rccl && (rc = ensure(c, c->w_xchg, (size_t)g * xwords * 8))) return fail(h, rc, c->err);
     }
     lap(2, tp);
     if ((rc = search_core(c, qn, b, k, kp, self0, oi, od, cs, allow, raw))) return fail(h, rc, c->err);
     lap(3, tp);
-    if (!direct) {
+    if (!direct && !rccl) {
       HIP_TRY(h, hipMemcpyPeerAsync(g_idx + (size_t)s * bk, h->device, oi, c->device, bk * 8, cs));
       HIP_TRY(h, hipMemcpyPeerAsync(g_dist + (size_t)s * bk, h->device, od, c->device, bk * 4, cs));
     }
-    if (!inline0) HIP_TRY(h, hipEventRecord(h->shard_done[(size_t)s], cs));
+    if (!inline0 && !rccl) HIP_TRY(h, hipEventRecord(h->shard_done[(size_t)s], cs));
     lap(4, tp);
+  }
+  if (rccl) {
+    // ONE all-gather of the packed per-shard results, every shard on its own stream (shard 0 on the caller's): the
+    // collective is the only cross-shard ordering — no completion events, no waits on the caller's stream
+    int nrc = g_rccl.GroupStart();
+    for (int s = 0; s < g && nrc == 0; ++s) {
+      vdb_t* c = h->shards[(size_t)s];
+      nrc = g_rccl.AllGather(c->w_out_i.p, c->w_xchg.p, xwords * 8, /*ncclChar*/ 0, h->comms[(size_t)s], (s == 0 && !h->shard_serial_streams) ? st : c->stream);
+    }
+    const int erc = g_rccl.GroupEnd();
+    if (nrc == 0) nrc = erc;
+    if (nrc != 0) return fail(h, VDB_ERR_DEVICE, "ncclAllGather: " + rccl_err(nrc));
+    if ((rc = set_device(h))) return rc;
+    vdb_t* c0 = h->shards[0];
+    if (h->shard_serial_streams) {   // shard 0 on a stream of its own: the caller's stream waits for its all-gather
+      HIP_TRY(h, hipEventRecord(h->shard_done[0], c0->stream));
+      HIP_TRY(h, hipStreamWaitEvent(st, h->shard_done[0], 0));
+    }
+    lap(5, tp);
+    hipLaunchKernelGGL(merge_shards_kernel, dim3(b), dim3(256), 0, st, (const float*)((const char*)c0->w_xchg.p + bk * 8), (long long)(2 * xwords),
+                       (const long long*)c0->w_xchg.p, (long long)xwords, g, k, (long long*)out_idx, out_dist);
+    HIP_TRY(h, hipGetLastError());
+    lap(6, tp);
+    return VDB_OK;
   }
   if ((rc = set_device(h))) return rc;
   for (int s = h->shard_serial_streams ? 0 : 1; s < g; ++s) HIP_TRY(h, hipStreamWaitEvent(st, h->shard_done[(size_t)s], 0));
@@ -1745,6 +1812,24 @@ int vdb_timing_stats(vdb_t* h, int64_t* n_searches, double* scan_ms_sum, double*
 
 int vdb_set_option(vdb_t* h, const char* name, int64_t value) {
   if (!h || !name) return VDB_ERR_ARG;
+  if (is_sharded(h) && !strcmp(name, "shard_exchange_rccl")) {
+    // 1: the shards' k results are exchanged by ONE RCCL all-gather (every shard receives all of them; shard 0 merges);
+    // 0 (default): each shard stores its results into shard 0's gather buffer (P2P)
+    if (!value) { for (void* c : h->comms) if (c) (void)g_rccl.CommDestroy(c); h->comms.clear(); return VDB_OK; }
+    if (!h->comms.empty()) return VDB_OK;
+    const int g = (int)h->shards.size();
+    std::vector<int> devs;
+    for (vdb_t* c : h->shards) devs.push_back(c->device);
+    for (int i = 0; i < g; ++i) for (int j = 0; j < i; ++j)
+      if (devs[i] == devs[j]) return fail(h, VDB_ERR_STATE, "shard_exchange_rccl: RCCL takes one rank per GPU; this handle has two shards on one device");
+    std::string why;
+    if (!load_rccl(&why)) return fail(h, VDB_ERR_STATE, why);
+    std::vector<void*> comms((size_t)g, nullptr);
+    const int rc = g_rccl.CommInitAll(comms.data(), g, devs.data());
+    if (rc != 0) return fail(h, VDB_ERR_DEVICE, "ncclCommInitAll: " + rccl_err(rc));
+    h->comms = comms;
+    return set_device(h);
+  }
   if (is_sharded(h) && !strcmp(name, "shard_force_remote")) { h->shard_force_remote = value != 0; return VDB_OK; }
   if (is_sharded(h) && !strcmp(name, "shard_own_stream_for_shard0")) { h->shard_serial_streams = value != 0; return VDB_OK; }
   if (is_sharded(h)) {   // every shard gets the same setting
@@ -1808,6 +1893,7 @@ int vdb_get_stat(vdb_t* h, const char* name, int64_t* value) {
   if (is_sharded(h)) {
     if (!strcmp(name, "rows_per_shard")) { *value = h->per; return VDB_OK; }
     if (!strcmp(name, "capacity_rows")) { *value = 0; for (vdb_t* c : h->shards) *value += c->cap; return VDB_OK; }
+    if (!strcmp(name, "shard_exchange_rccl")) { *value = h->comms.empty() ? 0 : 1; return VDB_OK; }
     if (!strcmp(name, "p2p_direct_shards")) { *value = 0; for (char d : h->shard_direct) *value += d; return VDB_OK; }
     if (!strncmp(name, "sharded_issue_phase_", 20) && name[20] >= '0' && name[20] <= '7') {   // ns per call since the last read of sharded_issue_ns_avg
       *value = h->issue_calls ? h->issue_phase_ns[name[20] - '0'] / h->issue_calls : 0;
