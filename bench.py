@@ -73,6 +73,8 @@ def parse_args():
                                                           "in a child process and report it as `inproc_sharded` (default when --gpus > 1)")
     ap.add_argument("--no-inproc", action="store_true")
     ap.add_argument("--inproc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--stream", default="default", choices=["default", "created", "created-high"],
+                    help="diagnostic: the stream the searches are issued on: the process' default (null) stream, a created one, or a created high-priority one")
     return ap.parse_args()
 
 
@@ -379,7 +381,22 @@ def measure(sh, args, b, steps, warmup, qspec, device, world, n_local):
     # Settle, then the W warm-up steps.  A fresh process sometimes runs its first few hundred milliseconds of kernels ~2 %
     # slow (clocks still ramping: two of four otherwise identical runs with 20 warm-up steps on one box); the same fixed
     # number of untimed steps on every rank (the steps are collective) takes the timed region past that.
+    # (round 3: at least ~0.8 s of them — benchmarks/stream_ab.py: a 1.25M-row step runs 0.306 ms for the first ~0.4 s of a
+    # loop and 0.295 ms from then on, whichever stream it is issued on; 150 steps of 0.3 ms ended before that)
     settle = 150 if b <= 64 else 8
+    for i in range(20):
+        step(i)
+    torch.cuda.synchronize()
+    t_est = time.perf_counter()
+    for i in range(20):
+        step(i)
+    torch.cuda.synchronize()
+    per_step = max((time.perf_counter() - t_est) / 20, 1e-6)
+    settle = max(settle, min(20000, int(0.8 / per_step)))
+    if world > 1:   # the steps are collective: every rank must run the SAME number of them
+        t = torch.tensor([settle], dtype=torch.int64, device=device if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        settle = int(t.item())
     for i in range(settle + warmup):
         step(i)
     torch.cuda.synchronize()
@@ -472,12 +489,11 @@ def measure(sh, args, b, steps, warmup, qspec, device, world, n_local):
         "value": steps * b / elapsed, "unit": "queries/s", "steps": steps, "warmup": warmup, "settle_steps_before_warmup": settle, "ms_per_step": 1e3 * elapsed / steps,
         "batch": b, "roofline": roof,
         "checks": {"planted_neighbour_first_and_ascending": planted_ok,
-                   # the bare-read probe (same launch shape and tile partition, no arithmetic) bounds the batched kernels; the
-                   # one-launch scan of round 3 streams 2-2.5 % FASTER than it (its FMAs space the waves' requests out; the probe
-                   # with one or two tiles in flight per wave, 2 or 4 blocks per CU, 25 launches each, tops out lower), so for
-                   # that kernel the probe is a reference point, not a ceiling: the vendor peak is the denominator that counts
+                   # measured_peak (HBM): the best of bare reads in the scan's launch shape and partition (one or two tiles in
+                   # flight per wave, with and without pauses) and of the scan's own loop with the selection taken out, each as
+                   # bursts of 24 back-to-back launches after 0.7 s of reads
                    "measured_peak_is_a_ceiling": (roof.get("frac_of_measured_peak") or 0) <= 1.02,
-                   "kernel_over_bare_read_probe": roof.get("frac_of_measured_peak"),
+
                    "mfma_overflow_fallback": sh.local.get_stat("mfma_last_overflow"),
                    "mfma_hits_per_query": sh.local.get_stat("mfma_last_hits") / b,
                    **({"prof": [sh.local.get_stat("mfma_prof_" + c) for c in "abcd"]} if args.ablate & 8 else {})},
@@ -559,6 +575,9 @@ def main():
     torch.cuda.synchronize()
     t_build = time.perf_counter() - t_build
 
+    if args.stream != "default":
+        lo_hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, -1)
+        torch.cuda.set_stream(torch.cuda.Stream(device, priority=min(lo_hi) if args.stream == "created-high" else 0))
     head = measure(sh, args, args.batch, args.steps, args.warmup, qspec, device, world, n_local)
     second = None
     if args.batch2 and args.batch2 != args.batch and args.dtype == "bf16":

@@ -35,6 +35,7 @@ struct FusedScanArgs {
   int rerank; const float* rows_f32; const uint16_t* rows_b16;   // fp32 copy (or nullptr: re-score against the bf16 rows)
   long long row_offset;
   long long* out_idx; float* out_dist;   // [qb][k]
+  int probe;                       // != 0 (stat probe_hbm_read_mbps): the lists accept nothing — the scan's own loop, loads and arithmetic, with the selection out
   long long* stamps;               // diagnostic (option "scan_stamps"): 100 MHz clock stamps, [16] of the last block + [grid][6]; else nullptr
 };
 constexpr int kFusedTicketBytes = 512;

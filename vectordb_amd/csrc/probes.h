@@ -48,7 +48,11 @@ __global__ __launch_bounds__(256) void probe_read_kernel(const v4u_t* __restrict
 // of the range its block group was dealt — the partition the scan's self-tuned per-XCD shares give, computed on the
 // host from the same share table — so that the figure stays a ceiling for a scan that balances its XCDs.
 struct ProbeRange { long long t_begin, t_end, wid0, nwv; };
-template <int U>
+// PACE: units of 64 cycles a wave idles between consuming a tile and asking for the next one.  The scan spends ~300-400
+// cycles of arithmetic there, which spaces its waves' requests out; a bare read that re-issues at once keeps all waves in
+// step with the memory latency and measured 2 % BELOW the scan.  With the pause the probe is a read in the scan's own
+// rhythm, and the best over a few pauses is the ceiling the scan is held against.
+template <int U, int PACE>
 __global__ __launch_bounds__(256) void probe_read_ranges_kernel(const v4u_t* __restrict__ p, const ProbeRange* __restrict__ rg, unsigned* __restrict__ sink) {
   const size_t lane = threadIdx.x & 63;
   const ProbeRange r = rg[blockIdx.x];
@@ -67,6 +71,7 @@ __global__ __launch_bounds__(256) void probe_read_ranges_kernel(const v4u_t* __r
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) acc ^= cur[u].x ^ cur[u].y ^ cur[u].z ^ cur[u].w;
+    if (PACE > 0) __builtin_amdgcn_s_sleep(PACE);
     if (more) {
 #pragma unroll
       for (int u = 0; u < U; ++u) cur[u] = nxt[u];

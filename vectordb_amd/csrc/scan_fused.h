@@ -146,7 +146,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_topk_fused_kernel(const Fus
 
   WaveTopK<1> tk[QB];
 #pragma unroll
-  for (int q = 0; q < QB; ++q) tk[q].init(kk);
+  for (int q = 0; q < QB; ++q) { tk[q].init(kk); if (a.probe) tk[q].thr_s = INFINITY; }   // probe: no row ever beats the threshold
 
   // ---- this wave's tiles.  The blocks of a launch do not stream at one rate (in-kernel stamps, profiles/r03_scan_stamps_*):
   // blocks b, b + 8, ... share an XCD, and with equal shares the odd XCDs of an MI355X need ~7 % longer than the even
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_topk_fused_kernel(const Fus
   const int grp = ((int)blockIdx.x & 7) + 8 * my_round;
   long long t_begin = 0, t_end = n_tiles, wid = (long long)blockIdx.x * kScanWaves + w, nwv = (long long)n_blocks * kScanWaves;
   unsigned* tune = a.ticket + kFusedDurOffset;          // [32] scan-time sums, then (kFusedShareOffset) [32] shares
-  const bool adapt = a.balance == 1 && !a.allow && n_tiles >= 32 * nwv;   // long enough a pass that the times mean something
+  const bool adapt = a.balance == 1 && !a.allow && !a.probe && n_tiles >= 32 * nwv;   // long enough a pass that the times mean something
   if (a.balance) {
     long long before = 0, mine = 0, total = 0;
     for (int g = 0; g < n_groups; ++g) {
