@@ -341,3 +341,46 @@ def test_rccl_exchange_behind_the_c_abi(hip_lib, oracle_mod):
         two.set_option("shard_exchange_rccl", 1)
     assert e.value.code == -5 and "one rank per GPU" in str(e.value)
     two.close()
+
+
+@pytest.mark.parametrize("dtype,dim,kp", [("f32", 768, 0), ("bf16", 768, 0), ("bf16", 384, 40), ("f32", 384, 0)])
+def test_group_launch_equals_one_launch_per_group(hip_lib, oracle_mod, dtype, dim, kp):
+    """A GEMV-path batch sends its whole groups of four queries as ONE 2-D launch (option scan_group_launch, the default):
+    same lists in the same places as one launch per group, so the same bits; checked against the oracle too, with a
+    where= bitmap, with the self-join's own-row exclusion, and across the 64-query chunk boundary."""
+    n = 23_457
+    spec = SynthSpec(seed=61, kind=1, n_clusters=151, noise=0.3)
+    qspec = SynthSpec(seed=62, kind=2, noise=0.5, base_kind=1, base_seed=61, base_n=n, base_n_clusters=151, base_noise=0.3)
+    rows = oracle_mod.normalize_rows(oracle_mod.synth_rows(0, n, dim, spec))
+    queries = oracle_mod.synth_rows(0, 135, dim, qspec)
+    qn = _qn(oracle_mod, queries)
+    ix = FlatIndex(dim, dtype, True)
+    ix.add_synth(0, n, spec)
+    ix.set_option("batch_mfma_min_b", 1 << 20)      # the scan, whatever the batch
+    rng = np.random.default_rng(7)
+    allow = rng.random(n) < 0.3
+    for b in (5, 8, 11, 30, 64, 67, 135):
+        for k in (10, 100):                          # 100: two list entries per lane
+            got = {}
+            for mode in (1, 0):
+                ix.set_option("scan_group_launch", mode)
+                got[mode] = (ix.search(queries[:b], k, kp if kp >= k else 0),
+                             ix.search_masked(queries[:b], k, allow, kp if kp >= k else 0))
+                assert ix.get_stat("last_corpus_passes") == (b // 4) + (1 if b % 4 >= 2 else 0) + (b % 2)
+            for (i1, d1), (i0, d0) in zip(got[1], got[0]):
+                assert np.array_equal(i1, i0) and np.array_equal(d1.view(np.uint32), d0.view(np.uint32)), f"{dtype} b={b} k={k}"
+            if dtype == "f32" or kp >= 4 * k:
+                r_idx, r_dist, r_sc = oracle_mod.exact_topk(rows, queries[:b], k)
+                check_topk(got[1][0][0], got[1][0][1], r_idx, r_dist, r_sc, rows, qn[:b], what=f"group launch {dtype} {dim} b={b} k={k}")
+                sub = np.flatnonzero(allow)
+                m_idx, m_dist, m_sc = oracle_mod.exact_topk(rows[sub], queries[:b], k)
+                check_topk(got[1][1][0], got[1][1][1], sub[m_idx], m_dist, m_sc, rows, qn[:b], what=f"group launch masked {dtype} {dim} b={b} k={k}")
+    # the self-join hands each query of a group its own row to skip
+    out = {}
+    for mode in (1, 0):
+        ix.set_option("scan_group_launch", mode)
+        out[mode] = ix.selfjoin(5, True, 0, 0, 1000)
+    assert np.array_equal(out[1][0], out[0][0]) and np.array_equal(out[1][1].view(np.uint32), out[0][1].view(np.uint32))
+    assert not (out[1][0] == np.arange(1000)[:, None]).any()
+    ix.set_option("scan_group_launch", 1)
+    ix.close()

@@ -165,3 +165,44 @@ def test_ephemeral_client(oracle_lib):
     assert c.get_or_create_collection("t", metadata={"hnsw:space": "cosine"}).count() == 1
     c.delete_collection("t")
     assert c.list_collections() == []
+
+
+def test_where_masks_are_kept_and_follow_the_collection(tmp_path, oracle_lib, monkeypatch):
+    """The `where=` predicate is evaluated once per row and predicate: a repeated filter re-uses its mask, rows added
+    since are evaluated on their own, and the answers are those of a fresh evaluation."""
+    import vectordb_amd.chroma_compat as cc
+    calls = {"n": 0}
+    real = cc._match_where
+
+    def counting(meta, where):
+        calls["n"] += 1
+        return real(meta, where)
+    monkeypatch.setattr(cc, "_match_where", counting)
+    client = PersistentClient(path=str(tmp_path), lib=oracle_lib)
+    col = client.get_or_create_collection(name="w", metadata={"hnsw:space": "cosine"})
+    rng = np.random.default_rng(3)
+    emb = rng.standard_normal((40, 8)).astype(np.float32)
+    metas = [{"kind": "abc"[i % 3], "rank": i} for i in range(40)]
+    col.add(embeddings=emb[:25], metadatas=metas[:25], ids=[f"i{i}" for i in range(25)])
+    w = {"kind": "b"}
+    first = col.query(query_embeddings=emb[:3], n_results=5, where=w)
+    assert calls["n"] == 25
+    again = col.query(query_embeddings=emb[:3], n_results=5, where={"kind": "b"})
+    assert calls["n"] == 25 and again["ids"] == first["ids"] and again["distances"] == first["distances"]
+    col.add(embeddings=emb[25:], metadatas=metas[25:], ids=[f"i{i}" for i in range(25, 40)])
+    grown = col.query(query_embeddings=emb[:3], n_results=40, where=w)
+    assert calls["n"] == 40                                       # only the 15 new rows
+    assert sorted(grown["ids"][0], key=lambda s: int(s[1:])) == [f"i{i}" for i in range(40) if i % 3 == 1]
+    fresh = PersistentClient(path=str(tmp_path), lib=oracle_lib).get_collection("w")
+    ref = fresh.query(query_embeddings=emb[:3], n_results=40, where=w)
+    assert ref["ids"] == grown["ids"] and ref["distances"] == grown["distances"]
+    # more predicates than the cache keeps, and one whose value json cannot key: all still answered exactly
+    for r in range(20):
+        got = col.query(query_embeddings=emb[:1], n_results=40, where={"rank": {"$gte": r}})
+        assert sorted(int(s[1:]) for s in got["ids"][0]) == list(range(r, 40))
+    assert len(col._where_cache) <= 16
+    got = col.query(query_embeddings=emb[:1], n_results=40, where={"rank": {"$in": [np.int64(3), 5]}})
+    assert sorted(got["ids"][0]) == ["i3", "i5"]
+    # a batch large enough for the temporary-shard route (few eligible rows, many passes) takes the same mask
+    big = col.query(query_embeddings=np.tile(emb[:4], (20, 1)), n_results=2, where={"rank": {"$in": [7]}})
+    assert all(ids == ["i7"] for ids in big["ids"])

@@ -214,6 +214,15 @@ __global__ __launch_bounds__(kScanThreads) void scan_topk_kernel(const void* __r
   using GM = ScanGeom<T, DIM>;
   constexpr int EPC = GM::EPC, CPR = GM::CPR, L = GM::L;
   const int lane = lane_id();
+  // blockIdx.y = which group of QB queries (a batch against a small store goes out as ONE launch of
+  // gridDim.y groups instead of gridDim.y launches; lists land where those launches would put them)
+  {
+    const size_t g = blockIdx.y;
+    qn += g * QB * DIM;
+    part_s += g * QB * gridDim.x * kk;
+    part_i += g * QB * gridDim.x * kk;
+    if (self0 >= 0) self0 += (int)g * QB;
+  }
 
   // per-lane query slices: load j of a group covers chunk (j*64+lane) % CPR of its row
   float qreg[QB][L][EPC];

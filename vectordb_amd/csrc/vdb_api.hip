@@ -117,6 +117,7 @@ struct vdb {
   // options
   int scan_blocks_per_cu = 2;    // 2 x 256 threads per CU: 96 KiB in flight per CU; 4 measured 3-4 % slower at every shard size (bf16)
   int scan_nt_loads = 1;
+  int scan_group_launch = 1;    // GEMV batches: all whole groups of four queries in one 2-D launch (0 = one launch per group)
   int batch_mfma_min_b = 2;      // smallest batch the MFMA path may serve (the cost model decides above it)
   bool mfma_attr_set = false;    // dynamic-LDS limits of the MFMA kernels raised on this handle's device
   int mfma_cost_model = 1;       // 0: every supported batch >= batch_mfma_min_b takes the MFMA path (tests)
@@ -465,15 +466,17 @@ int gemv_scan_chunk(vdb_t* h, const WsPtrs& W, const float* qn, int cb, int kk, 
   const bool fast = fast_dim(h);
   int q = 0;
   while (q < cb) {
-    int qb = 1;
+    int qb = 1, ny = 1;
     if (fast && e <= 2) { if (cb - q >= 4) qb = 4; else if (cb - q >= 2) qb = 2; }
+    // all whole groups of four go out as one 2-D launch (a batch against a small store is launch-bound otherwise)
+    if (qb == 4 && h->scan_group_launch) ny = (cb - q) / 4;
     ScanArgs a;
     a.rows = rows; a.n_rows = n_rows; a.qn = qn + (size_t)q * h->ld; a.kk = kk;
     a.self0 = self_row0 >= 0 ? (int)(self_row0 + q) : -1;
     a.allow = allow;
     a.part_s = W.ps + (size_t)q * grid * kk;
     a.part_i = W.pi + (size_t)q * grid * kk;
-    a.grid = grid; a.st = st;
+    a.grid = grid; a.st = st; a.ny = ny;
     a.smem = (size_t)4 * qb * kk * 8;   // 4 waves per scan block
     bool ok;
     const bool nt = h->scan_nt_loads != 0;
@@ -485,9 +488,9 @@ int gemv_scan_chunk(vdb_t* h, const WsPtrs& W, const float* qn, int cb, int kk, 
     }
     if (!ok) return fail(h, VDB_ERR_ARG, "search: unsupported k for this path");
     HIP_TRY(h, hipGetLastError());
-    h->last_bytes += (double)n_rows * h->ld * (bf16 ? 2 : 4);
-    h->last_passes++;
-    q += qb;
+    h->last_bytes += (double)ny * n_rows * h->ld * (bf16 ? 2 : 4);
+    h->last_passes += ny;
+    q += qb * ny;
   }
   return VDB_OK;
 }
@@ -1851,6 +1854,7 @@ int vdb_set_option(vdb_t* h, const char* name, int64_t value) {
     h->timing_every = (int)value; h->n_calls = 0; return VDB_OK;
   }
   if (!strcmp(name, "scan_nt_loads")) { h->scan_nt_loads = value != 0; return VDB_OK; }
+  if (!strcmp(name, "scan_group_launch")) { h->scan_group_launch = value != 0; return VDB_OK; }
   if (!strcmp(name, "stream_nt_loads")) { h->stream_nt = value != 0; return VDB_OK; }
   if (!strcmp(name, "mfma_ablate")) { h->mfma_ablate = (int)value; return VDB_OK; }
   if (!strcmp(name, "mfma_variant")) {

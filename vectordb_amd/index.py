@@ -133,18 +133,27 @@ class FlatIndex:
                                              idx.ctypes.data, dist.ctypes.data, rows.ctypes.data))
         return idx, dist, rows
 
-    def search_masked(self, queries, k: int, allow, rerank_kprime: int = 0) -> Tuple[np.ndarray, np.ndarray]:
+    @staticmethod
+    def pack_allow(allow: np.ndarray) -> np.ndarray:
+        """The bitmap vdb_search_masked takes: bit r of 32-bit word r/32 (little-endian) = row r is eligible."""
+        n = allow.shape[0]
+        bits = np.packbits(allow, bitorder="little")
+        words = np.zeros(max(1, (n + 31) // 32) * 4, np.uint8)
+        words[: bits.size] = bits
+        return words
+
+    def search_masked(self, queries, k: int, allow, rerank_kprime: int = 0, packed: Optional[np.ndarray] = None) -> Tuple[np.ndarray, np.ndarray]:
         """Exact top-k over the rows `allow` marks eligible (the `where=` pre-filter of
         collection.query, reference src/vectordb.py:230,259-264).  allow: boolean array,
-        one entry per stored row."""
+        one entry per stored row; packed: pack_allow(allow), for callers that keep it."""
         q = _as_f32_2d(queries, self.dim, "queries")
         allow = np.asarray(allow)
         n = self.count()
         if allow.dtype != np.bool_ or allow.shape != (n,):
             raise ValueError(f"allow must be a boolean array of shape ({n},), got {allow.dtype} {allow.shape}")
-        bits = np.packbits(allow, bitorder="little")
-        words = np.zeros(max(1, (n + 31) // 32) * 4, np.uint8)
-        words[: bits.size] = bits
+        words = packed if packed is not None else self.pack_allow(allow)
+        if words.dtype != np.uint8 or words.shape != (max(1, (n + 31) // 32) * 4,) or not words.flags.c_contiguous:
+            raise ValueError("packed must be pack_allow(allow)")
         b = q.shape[0]
         idx = np.empty((b, k), np.int64)
         dist = np.empty((b, k), np.float32)
