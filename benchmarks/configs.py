@@ -71,6 +71,7 @@ def main():
             col.query(query_embeddings=[q.tolist()], n_results=30, include=["metadatas", "distances", "embeddings"])
         api_us = (time.perf_counter() - t0) / len(qs) * 1e6
         ix = col._index
+        ix.set_option("timing_every", 1)      # the Collection switched the per-search timing events off; the engine-level rows below read them
         qd = torch.from_numpy(qs[:1].copy()).cuda()
         step, scan_ms, fin_ms = timed_search_dev(ix, qd, 1, 10, 0, 500, 20)
         q1 = qs[:1].copy()

@@ -127,6 +127,8 @@ class Collection:
         if self._index is None:
             self._dim = dim
             self._index = FlatIndex(dim, self._dtype, self._fp32_copy, self._device, lib=self._lib, devices=self._devices)
+            # nothing on this face reads vdb_last_timing: leave the three timing events per search out of the stream
+            self._index.set_option("timing_every", 65536)
         elif dim != self._dim:
             raise ValueError(f"Embedding dimension {dim} does not match collection dimensionality {self._dim}")
         return self._index
@@ -459,6 +461,7 @@ class Collection:
             if len(head) == 32 and int(np.frombuffer(head[16:24], dtype=np.int64)[0]) == count:
                 try:
                     self._index = FlatIndex.load(d, self._dtype, self._fp32_copy, self._device, lib=self._lib, devices=self._devices)
+                    self._index.set_option("timing_every", 65536)
                     self._vdb_rows = count
                     self._partition_rows = count          # vdb_load_sharded partitions for the file's row count
                     return
