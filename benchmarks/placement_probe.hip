@@ -105,6 +105,19 @@ int main(int argc, char** argv) {
     printf("VMM, physical chunks of %5zu MiB          : %7.1f GB/s\n", c >> 20, time_reads(b.va, bytes, sink));
     vmm_free(b);
   }
+  // behind a neighbour of growing size: does the rate follow the buffer's offset in the heap?
+  {
+    const double pads_gb[] = {0.0, 19.2, 38.4, 76.8, 153.6, 230.4, 38.4, 0.0};
+    for (double pg : pads_gb) {
+      void* pad = nullptr;
+      const size_t pb = (size_t)(pg * 1e9) / (2u << 20) * (2u << 20);
+      if (pb && hipMalloc(&pad, pb) != hipSuccess) { (void)hipGetLastError(); printf("pad %.1f GB: no memory\n", pg); continue; }
+      void* p; CHECK(hipMalloc(&p, bytes)); CHECK(hipMemset(p, 0x5a, bytes));
+      printf("hipMalloc behind a %5.1f GB neighbour        : %7.1f GB/s\n", pg, time_reads(p, bytes, sink));
+      CHECK(hipFree(p));
+      if (pad) CHECK(hipFree(pad));
+    }
+  }
   // a fragmented heap: 3000 buffers of 24 MiB, every other one freed, then the big allocation (the holes are 24 MiB)
   {
     std::vector<void*> small(3000, nullptr);
@@ -121,6 +134,11 @@ int main(int argc, char** argv) {
     void* p; CHECK(hipMalloc(&p, bytes)); CHECK(hipMemset(p, 0x5a, bytes));
     printf("hipMalloc beside a %.0f GB neighbour (%d)    : %7.1f GB/s\n", 2 * bytes / 1e9, rep, time_reads(p, bytes, sink));
     CHECK(hipFree(p)); CHECK(hipFree(big));
+  }
+  for (int rep = 0; rep < 2; ++rep) {
+    void* p; CHECK(hipMalloc(&p, bytes)); CHECK(hipMemset(p, 0x5a, bytes));
+    printf("hipMalloc alone again (%d)                  : %7.1f GB/s\n", rep, time_reads(p, bytes, sink));
+    CHECK(hipFree(p));
   }
   CHECK(hipFree(sink));
   return 0;

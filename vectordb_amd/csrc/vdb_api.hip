@@ -117,6 +117,7 @@ struct vdb {
   // options
   int scan_blocks_per_cu = 2;    // 2 x 256 threads per CU: 96 KiB in flight per CU; 4 measured 3-4 % slower at every shard size (bf16)
   int scan_nt_loads = 1;
+  int alloc_f32_first = 0;       // 1: allocate the fp32 copy before the bf16 rows (the order before round 3's placement finding)
   int scan_group_launch = 1;    // GEMV batches: all whole groups of four queries in one 2-D launch (0 = one launch per group)
   int batch_mfma_min_b = 2;      // smallest batch the MFMA path may serve (the cost model decides above it)
   bool mfma_attr_set = false;    // dynamic-LDS limits of the MFMA kernels raised on this handle's device
@@ -212,15 +213,20 @@ int grow(vdb_t* h, int64_t want_rows) {
   if (want_rows <= h->cap) return VDB_OK;
   want_rows = (want_rows + 255) / 256 * 256;   // the MFMA kernels read whole 256-row tiles (tail rows are masked)
   const size_t ld = (size_t)h->ld;
-  if (h->keep_f32) {
+  // The scanned array first: where a buffer lands in the heap changes the rate a streaming read of it gets by up to 6 %
+  // (benchmarks/placement_probe.hip: 19.2 GB read at 7.07 TB/s at the start of a fresh heap, 6.78 behind a 38.4 GB
+  // neighbour — which is where a 12.5M-row store's bf16 rows landed while its fp32 copy was allocated first).  The fp32
+  // copy is touched by the rerank's k' rows per query only.  (Option alloc_f32_first = 1: the old order, for A/B.)
+  auto grow_f32 = [&]() -> int {
     float* p = nullptr;
     HIP_TRY(h, hipMalloc((void**)&p, sizeof(float) * ld * (size_t)want_rows));
     if (h->n) HIP_TRY(h, hipMemcpyAsync(p, h->rows_f32, sizeof(float) * ld * (size_t)h->n, hipMemcpyDeviceToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (h->rows_f32) HIP_TRY(h, hipFree(h->rows_f32));
     h->rows_f32 = p;
-  }
-  if (h->dtype == VDB_BF16) {
+    return VDB_OK;
+  };
+  auto grow_b16 = [&]() -> int {
     uint16_t* p = nullptr;
     HIP_TRY(h, hipMalloc((void**)&p, sizeof(uint16_t) * ld * (size_t)want_rows));
     // rows beyond n are read (and masked) by the tiled kernels: keep them finite
@@ -229,6 +235,16 @@ int grow(vdb_t* h, int64_t want_rows) {
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (h->rows_bf16) HIP_TRY(h, hipFree(h->rows_bf16));
     h->rows_bf16 = p;
+    return VDB_OK;
+  };
+  int rc;
+  const bool b16 = h->dtype == VDB_BF16;
+  if (h->alloc_f32_first) {
+    if (h->keep_f32 && (rc = grow_f32())) return rc;
+    if (b16 && (rc = grow_b16())) return rc;
+  } else {
+    if (b16 && (rc = grow_b16())) return rc;
+    if (h->keep_f32 && (rc = grow_f32())) return rc;
   }
   h->cap = want_rows;
   return VDB_OK;
@@ -850,11 +866,11 @@ int vdb_rebalance(vdb_t* h, int64_t total_rows) {
     w.cap = (std::max(per, w.n) + 255) / 256 * 256;
     if (set_device(c) != VDB_OK) { drop(); return fail(h, VDB_ERR_DEVICE, c->err); }
     hipError_t e = hipSuccess;
-    if (c->keep_f32) e = hipMalloc((void**)&w.f32, sizeof(float) * ld * (size_t)w.cap);
-    if (e == hipSuccess && c->dtype == VDB_BF16) {
+    if (c->dtype == VDB_BF16) {   // the scanned array first, as in grow()
       e = hipMalloc((void**)&w.b16, sizeof(uint16_t) * ld * (size_t)w.cap);
       if (e == hipSuccess) e = hipMemset(w.b16, 0, sizeof(uint16_t) * ld * (size_t)w.cap);   // rows beyond n are read (and masked) by the tiled kernels
     }
+    if (e == hipSuccess && c->keep_f32) e = hipMalloc((void**)&w.f32, sizeof(float) * ld * (size_t)w.cap);
     // the old shards whose rows [o * old_per, o * old_per + n_o) overlap [lo, lo + w.n)
     for (int64_t o = 0; e == hipSuccess && o < g && w.n > 0; ++o) {
       vdb_t* src = h->shards[(size_t)o];
@@ -1855,6 +1871,7 @@ int vdb_set_option(vdb_t* h, const char* name, int64_t value) {
   }
   if (!strcmp(name, "scan_nt_loads")) { h->scan_nt_loads = value != 0; return VDB_OK; }
   if (!strcmp(name, "scan_group_launch")) { h->scan_group_launch = value != 0; return VDB_OK; }
+  if (!strcmp(name, "alloc_f32_first")) { h->alloc_f32_first = value != 0; return VDB_OK; }
   if (!strcmp(name, "stream_nt_loads")) { h->stream_nt = value != 0; return VDB_OK; }
   if (!strcmp(name, "mfma_ablate")) { h->mfma_ablate = (int)value; return VDB_OK; }
   if (!strcmp(name, "mfma_variant")) {
