@@ -384,3 +384,28 @@ def test_group_launch_equals_one_launch_per_group(hip_lib, oracle_mod, dtype, di
     assert not (out[1][0] == np.arange(1000)[:, None]).any()
     ix.set_option("scan_group_launch", 1)
     ix.close()
+
+
+def test_allocation_order_is_only_a_placement(hip_lib, oracle_mod):
+    """alloc_f32_first swaps the order in which a bf16 store's two arrays are allocated (the scanned rows go first by
+    default: heap placement changes a streaming read's rate, profiles/r03_placement.txt) — growth, answers and the
+    stored rows are the same either way."""
+    n, dim = 9_000, 768
+    spec = SynthSpec(seed=71, kind=1, n_clusters=90, noise=0.3)
+    rows = oracle_mod.synth_rows(0, n, dim, spec)
+    queries = rows[:5] + 0.05
+    got = []
+    for first in (0, 1):
+        ix = FlatIndex(dim, "bf16", True)
+        ix.set_option("alloc_f32_first", first)
+        for lo in range(0, n, 2_777):                 # several growth steps (copy into the new arrays, free the old)
+            ix.add(rows[lo:lo + 2_777])
+        got.append((ix.search(queries, 10, 40), ix.search(queries[:1], 10, 40), ix.fetch(np.arange(0, n, 997))))
+        ix.close()
+    for a, b in zip(got[0], got[1]):
+        if isinstance(a, tuple):
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+        else:
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    r_idx, _, _ = oracle_mod.exact_topk(oracle_mod.normalize_rows(rows), queries, 10)
+    assert np.array_equal(got[0][0][0][:, 0], r_idx[:, 0])
