@@ -33,17 +33,76 @@ __global__ __launch_bounds__(256) void read_kernel(const u32x4* __restrict__ p, 
   if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9e3779b9u) sink[0] = 1u;   // never true for the fill pattern: keeps the loads
 }
 
+// the same bytes as ONE moving window: 48 KiB pieces dealt round-robin to the blocks
+__global__ __launch_bounds__(256) void read_rr_kernel(const u32x4* __restrict__ p, size_t n_vec, unsigned* __restrict__ sink) {
+  u32x4 acc = {0u, 0u, 0u, 0u};
+  const size_t piece = 12 * 256;
+  for (size_t base = (size_t)blockIdx.x * piece; base + piece <= n_vec; base += (size_t)gridDim.x * piece) {
+    u32x4 v[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) v[j] = __builtin_nontemporal_load(p + base + threadIdx.x + (size_t)j * 256);
+#pragma unroll
+    for (int j = 0; j < 12; ++j) acc ^= v[j];
+  }
+  if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9e3779b9u) sink[0] = 1u;
+}
+// G moving windows: the buffer in G contiguous ranges, each dealt round-robin (48 KiB pieces) to gridDim.x / G blocks;
+// spread != 0: block b belongs to group b % G (the fused scan's classes: XCD = b & 7), else to group b / (gridDim.x / G)
+__global__ __launch_bounds__(256) void read_groups_kernel(const u32x4* __restrict__ p, size_t n_vec, unsigned* __restrict__ sink, int G, int spread) {
+  u32x4 acc = {0u, 0u, 0u, 0u};
+  const size_t piece = 12 * 256;
+  const int per_g = (int)gridDim.x / G;
+  const int g = spread ? (int)blockIdx.x % G : (int)blockIdx.x / per_g, j = spread ? (int)blockIdx.x / G : (int)blockIdx.x % per_g;
+  const size_t pieces = n_vec / piece, lo = pieces * g / G, hi = pieces * (g + 1) / G;
+  for (size_t t = lo + j; t < hi; t += per_g) {
+    const size_t base = t * piece;
+    u32x4 v[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) v[k] = __builtin_nontemporal_load(p + base + threadIdx.x + (size_t)k * 256);
+#pragma unroll
+    for (int k = 0; k < 12; ++k) acc ^= v[k];
+  }
+  if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9e3779b9u) sink[0] = 1u;
+}
+// ONE moving window made of per-XCD slices: super-rounds of 8 x 64 x c pieces; in each, XCD class g = b & 7 owns the
+// contiguous slice [g * 64c, (g + 1) * 64c) and deals it round-robin to its 64 blocks (c pieces each)
+__global__ __launch_bounds__(256) void read_super_kernel(const u32x4* __restrict__ p, size_t n_vec, unsigned* __restrict__ sink, int c) {
+  u32x4 acc = {0u, 0u, 0u, 0u};
+  const size_t piece = 12 * 256, pieces = n_vec / piece;
+  const int g = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3, per_g = (int)gridDim.x >> 3;
+  const size_t R = (size_t)8 * per_g * c;
+  for (size_t r = 0; r * R < pieces; ++r)
+    for (int k = 0; k < c; ++k) {
+      const size_t t = r * R + (size_t)g * per_g * c + (size_t)k * per_g + j;
+      if (t >= pieces) break;
+      const size_t base = t * piece;
+      u32x4 v[12];
+#pragma unroll
+      for (int q = 0; q < 12; ++q) v[q] = __builtin_nontemporal_load(p + base + threadIdx.x + (size_t)q * 256);
+#pragma unroll
+      for (int q = 0; q < 12; ++q) acc ^= v[q];
+    }
+  if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9e3779b9u) sink[0] = 1u;
+}
+static int g_rr = 0, g_groups = 0, g_spread = 0, g_super = 0;
+
 static double time_reads(const void* buf, size_t bytes, unsigned* sink) {
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
   const size_t n_vec = bytes / 16;
   const int warm = (int)std::max<size_t>(8, (size_t)(0.5 * 7e12 / (double)bytes));
-  for (int i = 0; i < warm; ++i) hipLaunchKernelGGL(read_kernel, dim3(512), dim3(256), 0, 0, (const u32x4*)buf, n_vec, sink);
+  auto launch = [&]() {
+    if (g_super) hipLaunchKernelGGL(read_super_kernel, dim3(512), dim3(256), 0, 0, (const u32x4*)buf, n_vec, sink, g_super);
+    else if (g_groups) hipLaunchKernelGGL(read_groups_kernel, dim3(512), dim3(256), 0, 0, (const u32x4*)buf, n_vec, sink, g_groups, g_spread);
+    else if (g_rr) hipLaunchKernelGGL(read_rr_kernel, dim3(512), dim3(256), 0, 0, (const u32x4*)buf, n_vec, sink);
+    else hipLaunchKernelGGL(read_kernel, dim3(512), dim3(256), 0, 0, (const u32x4*)buf, n_vec, sink);
+  };
+  for (int i = 0; i < warm; ++i) launch();
   CHECK(hipDeviceSynchronize());
   std::vector<double> r;
   for (int b = 0; b < 5; ++b) {
     CHECK(hipEventRecord(e0, 0));
-    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(read_kernel, dim3(512), dim3(256), 0, 0, (const u32x4*)buf, n_vec, sink);
+    for (int i = 0; i < 20; ++i) launch();
     CHECK(hipEventRecord(e1, 0));
     CHECK(hipEventSynchronize(e1));
     float ms = 0.f;
@@ -92,6 +151,36 @@ int main(int argc, char** argv) {
   CHECK(hipSetDevice(0));
   unsigned* sink; CHECK(hipMalloc(&sink, 256)); CHECK(hipMemset(sink, 0, 256));
   printf("buffer %.2f GB\n", bytes / 1e9);
+  if (argc > 2) {   // windows of ONE large allocation on a fresh heap: is the rate a property of the region?
+    const int n_win = atoi(argv[2]);
+    char* big; CHECK(hipMalloc((void**)&big, bytes * (size_t)n_win)); CHECK(hipMemset(big, 0x5a, bytes * (size_t)n_win));
+    for (int rep = 0; rep < 1; ++rep)
+      for (int k = 0; k < n_win; ++k) {
+        g_rr = 0; const double a = time_reads(big + (size_t)k * bytes, bytes, sink);
+        g_rr = 1; const double b = time_reads(big + (size_t)k * bytes, bytes, sink);
+        g_rr = 0;
+        printf("window %2d of one %.0f GB allocation (%d)   : %7.1f GB/s as 512 ranges, %7.1f as one moving window\n", k, n_win * bytes / 1e9, rep, a, b);
+      }
+    // how many concurrent windows does it take?  slow and fast windows of the list above, G = 1 ... 512 groups
+    for (int k : {0, 3, 7, 9, 10}) {
+      if (k >= n_win) continue;
+      printf("window %2d, G moving windows (blocks b/(512/G) | b%%G):", k);
+      for (int G : {1, 2, 4, 8, 16, 32, 64, 128, 512}) {
+        g_groups = G; g_spread = 0; const double a = time_reads(big + (size_t)k * bytes, bytes, sink);
+        g_spread = 1; const double b = time_reads(big + (size_t)k * bytes, bytes, sink);
+        printf("  G=%d %6.0f|%6.0f", G, a, b);
+      }
+      g_groups = 0; g_spread = 0;
+      printf("\n");
+      printf("window %2d, one window of per-XCD slices, c pieces per block and super-round:", k);
+      for (int c : {1, 2, 4, 8, 16, 64}) { g_super = c; printf("  c=%d %6.0f", c, time_reads(big + (size_t)k * bytes, bytes, sink)); }
+      g_super = 0;
+      printf("\n");
+    }
+    CHECK(hipFree(big));
+    CHECK(hipFree(sink));
+    return 0;
+  }
   for (int rep = 0; rep < 2; ++rep) {
     void* p; CHECK(hipMalloc(&p, bytes)); CHECK(hipMemset(p, 0x5a, bytes));
     printf("hipMalloc, fresh heap (%d)               : %7.1f GB/s\n", rep, time_reads(p, bytes, sink));

@@ -47,7 +47,10 @@ __global__ __launch_bounds__(256) void probe_read_kernel(const v4u_t* __restrict
 // The same bare read in the FUSED scan's launch shape (scan_fused.h): block b's waves take tiles t_begin + wid, + nwv, ...
 // of the range its block group was dealt — the partition the scan's self-tuned per-XCD shares give, computed on the
 // host from the same share table — so that the figure stays a ceiling for a scan that balances its XCDs.
-struct ProbeRange { long long t_begin, t_end, wid0, nwv; };
+// A block's place in the fused scan's tile partition (TileWalk, scan_gemv.h): member s of its class's sequence lies at
+// base + (s / q) * R + s % q while s < full_q, at tail_base + (s - full_q) behind that; the block's four waves are
+// members wid0 ... wid0 + 3 of every nwv.
+struct ProbeRange { int wid0, nwv, n_seq, base, q, R, full_q, tail_base; };
 // PACE: units of 64 cycles a wave idles between consuming a tile and asking for the next one.  The scan spends ~300-400
 // cycles of arithmetic there, which spaces its waves' requests out; a bare read that re-issues at once keeps all waves in
 // step with the memory latency and measured 2 % BELOW the scan.  With the pause the probe is a read in the scan's own
@@ -58,16 +61,21 @@ __global__ __launch_bounds__(256) void probe_read_ranges_kernel(const v4u_t* __r
   const ProbeRange r = rg[blockIdx.x];
   unsigned acc = 0;
   v4u_t cur[U], nxt[U];
-  long long t = r.t_begin + r.wid0 + (threadIdx.x >> 6);
-  if (t < r.t_end) {
+  auto tile_of = [&](int s) -> size_t {
+    return s < r.full_q ? (size_t)r.base + (size_t)(s / r.q) * (size_t)r.R + (size_t)(s % r.q) : (size_t)r.tail_base + (size_t)(s - r.full_q);
+  };
+  int s = r.wid0 + (int)(threadIdx.x >> 6);
+  if (s < r.n_seq) {
+    const size_t t = tile_of(s);
 #pragma unroll
-    for (int u = 0; u < U; ++u) cur[u] = __builtin_nontemporal_load(p + (size_t)t * (U * 64) + lane + u * 64);
+    for (int u = 0; u < U; ++u) cur[u] = __builtin_nontemporal_load(p + t * (U * 64) + lane + u * 64);
   }
-  for (; t < r.t_end; t += r.nwv) {
-    const bool more = t + r.nwv < r.t_end;
+  for (; s < r.n_seq; s += r.nwv) {
+    const bool more = s + r.nwv < r.n_seq;
     if (more) {
+      const size_t t = tile_of(s + r.nwv);
 #pragma unroll
-      for (int u = 0; u < U; ++u) nxt[u] = __builtin_nontemporal_load(p + (size_t)(t + r.nwv) * (U * 64) + lane + u * 64);
+      for (int u = 0; u < U; ++u) nxt[u] = __builtin_nontemporal_load(p + t * (U * 64) + lane + u * 64);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) acc ^= cur[u].x ^ cur[u].y ^ cur[u].z ^ cur[u].w;

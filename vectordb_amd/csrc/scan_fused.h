@@ -30,6 +30,7 @@ namespace vdbk {
 constexpr int kFusedSurvivorCap = 2048;     // (score, index) pairs the last block keeps in LDS
 static_assert(kFusedMaxParts == 4 * kScanThreads, "the bound step holds 4 list heads per thread");
 constexpr int kFusedRerankRows = 10;        // rows a wave re-scores at a time (30 x 16 bytes in flight per lane at 768-d: k' = 40 in ONE round trip)
+constexpr int kFusedTilesPerWaveAndRound = kFusedTilesPerWaveAndRoundC;   // super-round = this many tiles per wave of the grid (512 blocks: 8192 tiles = 100 MB of 768-d bf16)
 constexpr int kFusedSweepAhead = 20;        // 16-byte loads per thread of one sweep round (512 lists x 40 = one round)
 
 // LDS of the last block's epilogue, behind the block merge area (see fused_smem_bytes)
@@ -152,7 +153,8 @@ __global__ __launch_bounds__(kScanThreads) void scan_topk_fused_kernel(const Fus
   // blocks b, b + 8, ... share an XCD, and with equal shares the odd XCDs of an MI355X need ~7 % longer than the even
   // ones (2170 vs 2030 us per 10M-row pass); and the SECOND block a CU receives (b >= the CU count) runs 2.5-4.5 %
   // behind the first.  The pass ends with the slowest block.  So the blocks form groups (b & 7, b / n_cu), each group
-  // gets a contiguous range of tiles in proportion to share[group] x its blocks, and the shares TUNE THEMSELVES: every
+  // gets tiles in proportion to share[group] x its blocks — a slice of every super-round, so that the grid still walks
+  // the corpus as one window (TileWalk, scan_gemv.h) — and the shares TUNE THEMSELVES: every
   // block adds its scan time to its group's sum, and the last block turns the sums into the next launch's shares
   // (below).  The partition is a function of the share table alone, so it is exact whatever the table holds.
   // (Tried first and measured slower than the uneven static split: claiming the last fifth of the tiles from work pools
@@ -169,9 +171,9 @@ __global__ __launch_bounds__(kScanThreads) void scan_topk_fused_kernel(const Fus
   };
   const int my_round = min((int)blockIdx.x / n_cu, (n_groups >> 3) - 1);
   const int grp = ((int)blockIdx.x & 7) + 8 * my_round;
-  long long t_begin = 0, t_end = n_tiles, wid = (long long)blockIdx.x * kScanWaves + w, nwv = (long long)n_blocks * kScanWaves;
+  TileWalk wk = TileWalk::plain(n_tiles, (long long)blockIdx.x * kScanWaves + w, (long long)n_blocks * kScanWaves);
   unsigned* tune = a.ticket + kFusedDurOffset;          // [32] scan-time sums, then (kFusedShareOffset) [32] shares
-  const bool adapt = a.balance == 1 && !a.allow && !a.probe && n_tiles >= 32 * nwv;   // long enough a pass that the times mean something
+  const bool adapt = a.balance == 1 && !a.allow && !a.probe && n_tiles >= 32 * (long long)wk.nwv;   // long enough a pass that the times mean something
   if (a.balance) {
     long long before = 0, mine = 0, total = 0;
     for (int g = 0; g < n_groups; ++g) {
@@ -181,13 +183,21 @@ __global__ __launch_bounds__(kScanThreads) void scan_topk_fused_kernel(const Fus
       if (g == grp) mine = wgt;
       total += wgt;
     }
-    t_begin = n_tiles * before / total;
-    t_end = n_tiles * (before + mine) / total;
-    wid = (long long)(((int)blockIdx.x - my_round * n_cu) >> 3) * kScanWaves + w;
-    nwv = (long long)group_blocks(grp) * kScanWaves;
+    // super-rounds of kFusedTilesPerWaveAndRound tiles per wave of the grid: the class owns [S_g, S_g + q) of each;
+    // what is left behind the last full one (all of a small store) is split by the same weights (TileWalk, scan_gemv.h)
+    const long long R = (long long)kFusedTilesPerWaveAndRound * n_blocks * kScanWaves;
+    const long long full = a.super_rounds ? n_tiles / R : 0, rem = n_tiles - full * R;
+    const long long s_lo = R * before / total, s_hi = R * (before + mine) / total;
+    const long long t_lo = rem * before / total, t_hi = rem * (before + mine) / total;
+    wk.wid = (((int)blockIdx.x - my_round * n_cu) >> 3) * kScanWaves + w;
+    wk.nwv = group_blocks(grp) * kScanWaves;
+    wk.base = (int)s_lo; wk.q = (int)(s_hi - s_lo); wk.R = (int)R;
+    wk.full_q = (int)(full * (s_hi - s_lo));
+    wk.tail_base = (int)(full * R + t_lo);
+    wk.n_seq = wk.full_q + (int)(t_hi - t_lo);
   }
   const long long clock0 = (long long)wall_clock64();
-  scan_corpus_tiles<T, DIM, QB, 1, NT>(a.rows, a.n_rows, qreg, tk, a.self0, a.allow, t_begin, t_end, wid, nwv);
+  scan_corpus_tiles<T, DIM, QB, 1, NT>(a.rows, a.n_rows, qreg, tk, a.self0, a.allow, wk);
   if (adapt && threadIdx.x == 0)
     __hip_atomic_fetch_add(tune + grp, (unsigned)((long long)wall_clock64() - clock0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 

@@ -172,20 +172,40 @@ __device__ __forceinline__ void scan_one_tile(const u32x4* __restrict__ rows, in
   }
 }
 
-// The corpus pass of one wave: tiles t_begin + wid, t_begin + wid + nwv, ... below t_end, every one scored against the
-// QB queries in qreg, winners into tk.  The plain scan deals the whole corpus out over all waves of the grid
-// (t_begin = 0, wid = the wave's number in the grid); the fused kernel deals each class of blocks a range of its own
-// (scan_fused.h: the XCDs of an MI355X do not stream at one rate).
+// Which tiles a wave visits.  The waves that share a SEQUENCE of tiles (all waves of the grid in the plain scan; the
+// waves of one class of blocks in the fused kernel) take its members wid, wid + nwv, ... < n_seq.  Member s of a sequence
+// lies in super-round s / q at offset s % q — the class owns the q tiles from `base` on in each of the first
+// full_q / q super-rounds of R tiles — and behind those in a last range of its own from tail_base on.
+// Why super-rounds: the whole grid then walks the corpus as ONE window (a few tens of MB wide), each class on its own
+// slice of it.  Streams that walk ranges of their own far apart (1.2 GB: the 16 class ranges this kernel used first)
+// lose ~5 % of the read rate in SOME regions of HBM, any two such streams are enough (benchmarks/placement_probe.hip,
+// profiles/r03_placement.txt: 6.7 vs 7.07 TB/s, the same windows of one allocation every time), which made a store's
+// scan rate depend on where it was allocated; one window of per-XCD slices reads 7.15-7.19 TB/s in every region.
+struct TileWalk {
+  int wid, nwv, n_seq;
+  int base, q, R, full_q, tail_base;
+  __device__ __forceinline__ static TileWalk plain(long long n_tiles, long long wid_, long long nwv_) {
+    return TileWalk{(int)wid_, (int)nwv_, (int)n_tiles, 0, 0, 0, 0, 0};
+  }
+};
+
+// The corpus pass of one wave: every tile of its walk scored against the QB queries in qreg, winners into tk.
 template <typename T, int DIM, int QB, int E, bool NT>
 __device__ __forceinline__ void scan_corpus_tiles(const void* __restrict__ rows_v, int n_rows,
                                                   const float (&qreg)[QB][ScanGeom<T, DIM>::L][ScanGeom<T, DIM>::EPC],
                                                   WaveTopK<E> (&tk)[QB], int self0, const unsigned* __restrict__ allow,
-                                                  long long t_begin, long long t_end, long long wid, long long nwv) {
+                                                  const TileWalk wk) {
   using GM = ScanGeom<T, DIM>;
   constexpr int CPR = GM::CPR, RPT = GM::RPT;
   const u32x4* __restrict__ rows = reinterpret_cast<const u32x4*>(rows_v);
   const long long total_chunks = (long long)n_rows * CPR;
-  const long long first = t_begin + wid;
+
+  // position of member s inside the super-rounds: round r, offset o (one division per wave, then increments)
+  int s = wk.wid, r = 0, o = 0;
+  if (wk.full_q > 0) { r = s / wk.q; o = s - r * wk.q; }
+  auto tile_of = [&](int s_, int r_, int o_) -> long long {
+    return s_ < wk.full_q ? (long long)wk.base + (long long)r_ * wk.R + o_ : (long long)wk.tail_base + (s_ - wk.full_q);
+  };
 
   // eligibility bits of a tile's rows (bit j = row tile*RPT + j), fetched ONE TILE AHEAD so that the (wave-uniform)
   // load hides behind the current tile; a tile with no eligible row is not read at all, so a selective where=
@@ -195,13 +215,20 @@ __device__ __forceinline__ void scan_corpus_tiles(const void* __restrict__ rows_
     const long long r0 = t * RPT;
     return (allow[r0 >> 5] >> (unsigned)(r0 & 31)) & kTileBits;
   };
-  unsigned elig_next = (allow && first < t_end) ? tile_bits(first) : kTileBits;
+  long long tile = s < wk.n_seq ? tile_of(s, r, o) : 0;
+  unsigned elig_next = (allow && s < wk.n_seq) ? tile_bits(tile) : kTileBits;
 
-  for (long long tile = first; tile < t_end; tile += nwv) {
+  while (s < wk.n_seq) {
+    const long long here = tile;
     const unsigned elig = elig_next;
-    if (allow && tile + nwv < t_end) elig_next = tile_bits(tile + nwv);
+    s += wk.nwv;
+    if (wk.full_q > 0) { o += wk.nwv; while (o >= wk.q) { o -= wk.q; ++r; } }
+    if (s < wk.n_seq) {
+      tile = tile_of(s, r, o);
+      if (allow) elig_next = tile_bits(tile);
+    }
     if (elig == 0u) continue;
-    scan_one_tile<T, DIM, QB, E, NT>(rows, n_rows, total_chunks, tile, elig, qreg, tk, self0);
+    scan_one_tile<T, DIM, QB, E, NT>(rows, n_rows, total_chunks, here, elig, qreg, tk, self0);
   }
 }
 
@@ -240,8 +267,9 @@ __global__ __launch_bounds__(kScanThreads) void scan_topk_kernel(const void* __r
   for (int q = 0; q < QB; ++q) tk[q].init(kk);
 
   constexpr int RPT = GM::RPT;
-  scan_corpus_tiles<T, DIM, QB, E, NT>(rows_v, n_rows, qreg, tk, self0, allow, 0, ((long long)n_rows + RPT - 1) / RPT,
-                                       (long long)blockIdx.x * kScanWaves + (threadIdx.x >> 6), (long long)gridDim.x * kScanWaves);
+  scan_corpus_tiles<T, DIM, QB, E, NT>(rows_v, n_rows, qreg, tk, self0, allow,
+                                       TileWalk::plain(((long long)n_rows + RPT - 1) / RPT, (long long)blockIdx.x * kScanWaves + (threadIdx.x >> 6),
+                                                       (long long)gridDim.x * kScanWaves));
   block_merge_store<QB, E>(tk, kk, part_s, part_i, gridDim.x, blockIdx.x);
 }
 

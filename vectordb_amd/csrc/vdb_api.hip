@@ -118,6 +118,7 @@ struct vdb {
   int scan_blocks_per_cu = 2;    // 2 x 256 threads per CU: 96 KiB in flight per CU; 4 measured 3-4 % slower at every shard size (bf16)
   int scan_nt_loads = 1;
   int alloc_f32_first = 0;       // 1: allocate the fp32 copy before the bf16 rows (the order before round 3's placement finding)
+  int scan_super_rounds = 1;     // fused scan: the block groups' tiles interleave in super-rounds (one window over the corpus); 0 = a contiguous range per group
   int scan_group_launch = 1;    // GEMV batches: all whole groups of four queries in one 2-D launch (0 = one launch per group)
   int batch_mfma_min_b = 2;      // smallest batch the MFMA path may serve (the cost model decides above it)
   bool mfma_attr_set = false;    // dynamic-LDS limits of the MFMA kernels raised on this handle's device
@@ -542,7 +543,7 @@ int gemv_fused(vdb_t* h, const WsPtrs& W, unsigned* ticket, const float* q, bool
     a.kk = kk; a.k = k; a.kks = round_up(kk, 4);
     a.self0 = self_row0 >= 0 ? (int)(self_row0 + qd) : -1; a.allow = allow;
     a.part_s = W.ps; a.part_i = W.pi;          // the next launch reuses them (stream order)
-    a.ticket = ticket; a.balance = h->scan_balance; a.n_cu = h->n_cu;
+    a.ticket = ticket; a.balance = h->scan_balance; a.super_rounds = h->scan_super_rounds; a.n_cu = h->n_cu;
     a.rerank = kp != 0; a.rows_f32 = h->keep_f32 ? h->rows_f32 : nullptr; a.rows_b16 = h->rows_bf16;
     a.row_offset = (long long)h->row_offset;
     a.out_idx = (long long*)out_idx + (size_t)qd * k; a.out_dist = out_dist + (size_t)qd * k;
@@ -1871,6 +1872,7 @@ int vdb_set_option(vdb_t* h, const char* name, int64_t value) {
   }
   if (!strcmp(name, "scan_nt_loads")) { h->scan_nt_loads = value != 0; return VDB_OK; }
   if (!strcmp(name, "scan_group_launch")) { h->scan_group_launch = value != 0; return VDB_OK; }
+  if (!strcmp(name, "scan_super_rounds")) { h->scan_super_rounds = value != 0; return VDB_OK; }
   if (!strcmp(name, "alloc_f32_first")) { h->alloc_f32_first = value != 0; return VDB_OK; }
   if (!strcmp(name, "stream_nt_loads")) { h->stream_nt = value != 0; return VDB_OK; }
   if (!strcmp(name, "mfma_ablate")) { h->mfma_ablate = (int)value; return VDB_OK; }
@@ -2025,10 +2027,17 @@ int vdb_get_stat(vdb_t* h, const char* name, int64_t* value) {
       std::vector<long long> before(n_groups + 1, 0);
       for (int g = 0; g < n_groups; ++g) before[g + 1] = before[g] + (long long)(share[g] ? share[g] : kFusedShareUnit) * group_blocks(g);
       std::vector<ProbeRange> rg((size_t)n_blocks);
-      for (int b = 0; b < n_blocks; ++b) {
+      const long long R = (long long)kFusedTilesPerWaveAndRoundC * n_blocks * 4, full = h->scan_super_rounds ? n_tiles / R : 0, rem = n_tiles - full * R, total = before[n_groups];
+      for (int b = 0; b < n_blocks; ++b) {   // the partition of scan_topk_fused_kernel (scan_fused.h), block by block
         const int round = std::min(b / n_cu, rounds - 1), grp = (b & 7) + 8 * round;
-        rg[(size_t)b] = ProbeRange{n_tiles * before[grp] / before[n_groups], n_tiles * before[grp + 1] / before[n_groups],
-                                   (long long)((b - round * n_cu) >> 3) * 4, (long long)group_blocks(grp) * 4};
+        const long long s_lo = R * before[grp] / total, s_hi = R * before[grp + 1] / total;
+        const long long t_lo = rem * before[grp] / total, t_hi = rem * before[grp + 1] / total;
+        ProbeRange r;
+        r.wid0 = ((b - round * n_cu) >> 3) * 4; r.nwv = group_blocks(grp) * 4;
+        r.base = (int)s_lo; r.q = (int)(s_hi - s_lo); r.R = (int)R; r.full_q = (int)(full * (s_hi - s_lo));
+        r.tail_base = (int)(full * R + t_lo); r.n_seq = r.full_q + (int)(t_hi - t_lo);
+        if (r.q <= 0) { r.q = 1; r.full_q = 0; r.n_seq = (int)(t_hi - t_lo); }
+        rg[(size_t)b] = r;
       }
       if ((rc = ensure(h, h->w_idx, rg.size() * sizeof(ProbeRange)))) return rc;
       HIP_TRY(h, hipMemcpy(h->w_idx.p, rg.data(), rg.size() * sizeof(ProbeRange), hipMemcpyHostToDevice));
@@ -2067,7 +2076,7 @@ int vdb_get_stat(vdb_t* h, const char* name, int64_t* value) {
         memset(&a, 0, sizeof a);
         a.rows = h->dtype == VDB_BF16 ? (const void*)h->rows_bf16 : (const void*)h->rows_f32; a.n_rows = (int)h->n;
         a.q = (const float*)h->w_q.p; a.normalize = 0; a.kk = 40; a.k = 10; a.kks = 40; a.self0 = -1;
-        a.part_s = P.ps; a.part_i = P.pi; a.ticket = (unsigned*)h->w_ticket.p; a.balance = h->scan_balance; a.n_cu = h->n_cu;
+        a.part_s = P.ps; a.part_i = P.pi; a.ticket = (unsigned*)h->w_ticket.p; a.balance = h->scan_balance; a.super_rounds = h->scan_super_rounds; a.n_cu = h->n_cu;
         a.rerank = 0; a.rows_b16 = h->rows_bf16; a.out_idx = (long long*)h->w_out_i.p; a.out_dist = (float*)((char*)h->w_out_i.p + 64 * 8);
         a.probe = 1;
         HIP_TRY(h, hipEventRecord(e0, ps));
