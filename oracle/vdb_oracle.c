@@ -583,7 +583,7 @@ int vdb_timing_stats(vdb_t* h, int64_t* n, double* a, double* b, int reset) {
 int vdb_set_option(vdb_t* h, const char* name, int64_t value) {
   (void)value;
   if (!h || !name) return VDB_ERR_ARG;
-  if (!strcmp(name, "mfma_variant") || !strcmp(name, "mfma_cost_model") || !strcmp(name, "mfma_force_fallback") || !strcmp(name, "mfma_append_cap") || !strcmp(name, "mfma_ablate") || !strcmp(name, "timing_ring") || !strcmp(name, "timing_every") || !strcmp(name, "mfma_split_x1000") || !strcmp(name, "mfma_skip_sample") || !strcmp(name, "scan_blocks_per_cu") || !strcmp(name, "scan_nt_loads") || !strcmp(name, "scan_group_launch") || !strcmp(name, "alloc_f32_first") || !strcmp(name, "scan_super_rounds") || !strcmp(name, "batch_mfma_min_b") || !strcmp(name, "stream_nt_loads")) return VDB_OK;
+  if (!strcmp(name, "mfma_variant") || !strcmp(name, "mfma_cost_model") || !strcmp(name, "mfma_force_fallback") || !strcmp(name, "mfma_append_cap") || !strcmp(name, "mfma_ablate") || !strcmp(name, "timing_ring") || !strcmp(name, "timing_every") || !strcmp(name, "mfma_split_x1000") || !strcmp(name, "mfma_skip_sample") || !strcmp(name, "scan_blocks_per_cu") || !strcmp(name, "scan_nt_loads") || !strcmp(name, "scan_group_launch") || !strcmp(name, "alloc_f32_first") || !strcmp(name, "stream_xcd_slices") || !strcmp(name, "scan_xcd_slices") || !strcmp(name, "scan_super_rounds") || !strcmp(name, "batch_mfma_min_b") || !strcmp(name, "stream_nt_loads")) return VDB_OK;
   return fail(h, VDB_ERR_ARG, "set_option: unknown option");
 }
 

@@ -9,9 +9,9 @@ namespace {
 template <typename T, int DIM, int QB, int E>
 void launch_scan_t(const ScanArgs& a, bool nt) {
   if (nt)
-    hipLaunchKernelGGL((scan_topk_kernel<T, DIM, QB, E, true>), dim3(a.grid, a.ny > 0 ? a.ny : 1), dim3(kScanThreads), a.smem, a.st, a.rows, a.n_rows, a.qn, a.kk, a.self0, a.allow, a.part_s, a.part_i);
+    hipLaunchKernelGGL((scan_topk_kernel<T, DIM, QB, E, true>), dim3(a.grid, a.ny > 0 ? a.ny : 1), dim3(kScanThreads), a.smem, a.st, a.rows, a.n_rows, a.qn, a.kk, a.self0, a.allow, a.part_s, a.part_i, a.xcd_slices);
   else
-    hipLaunchKernelGGL((scan_topk_kernel<T, DIM, QB, E, false>), dim3(a.grid, a.ny > 0 ? a.ny : 1), dim3(kScanThreads), a.smem, a.st, a.rows, a.n_rows, a.qn, a.kk, a.self0, a.allow, a.part_s, a.part_i);
+    hipLaunchKernelGGL((scan_topk_kernel<T, DIM, QB, E, false>), dim3(a.grid, a.ny > 0 ? a.ny : 1), dim3(kScanThreads), a.smem, a.st, a.rows, a.n_rows, a.qn, a.kk, a.self0, a.allow, a.part_s, a.part_i, a.xcd_slices);
 }
 
 template <typename T, int DIM>

@@ -14,6 +14,7 @@ namespace vdbk {
 struct ScanArgs {
   const void* rows; int n_rows; const float* qn; int kk; int self0; const unsigned* allow; float* part_s; int* part_i;
   int grid; hipStream_t st; size_t smem;
+  int xcd_slices = 1;        // fast kernel only: blocks of one XCD take adjacent tiles (0: block-by-block round-robin)
   int ny = 1;                // fast kernel only: groups of qb queries in this launch (grid.y); group g reads qn + g*qb*dim, writes part + g*qb*grid*kk
 };
 // compile-time row length (768 or 384), qb in {1,2,4} queries per corpus pass, e = list entries per lane

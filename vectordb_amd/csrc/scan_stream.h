@@ -63,7 +63,7 @@ template <int MODE, int NQ, bool NT>
 __global__ __launch_bounds__(kStThreads, 2) void scan_stream_lds_kernel(
     const unsigned char* __restrict__ rows, int n_rows, const unsigned char* __restrict__ qb16, int b,
     int n_pass_tiles, int tile_stride, int skip_n, int self0, const float* __restrict__ thr_in,
-    float* __restrict__ dense, int* __restrict__ cand_cnt, float* __restrict__ cand_s, int* __restrict__ cand_i, int cap) {
+    float* __restrict__ dense, int* __restrict__ cand_cnt, float* __restrict__ cand_s, int* __restrict__ cand_i, int cap, int xcd_slices) {
   extern __shared__ __align__(16) unsigned char smem[];   // [query image][8 waves x kStSlabs slabs]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -88,7 +88,11 @@ __global__ __launch_bounds__(kStThreads, 2) void scan_stream_lds_kernel(
 
   const long long n_units = (long long)n_pass_tiles * kStSub;
   const long long nw = (long long)gridDim.x * kStWaves;
-  long long u = (long long)blockIdx.x * kStWaves + w;
+  // blocks b, b + 8, ... share an XCD: with xcd_slices they take ADJACENT units, so that each grid-wide step is eight
+  // contiguous per-XCD slices of one window (the read probe: 7.15-7.19 TB/s against 7.06-7.09 for block-by-block
+  // round-robin, profiles/r03_placement.txt)
+  const int blk = (xcd_slices && (gridDim.x & 7u) == 0u) ? (int)((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
+  long long u = (long long)blk * kStWaves + w;
   if (u >= n_units) return;
   auto unit_row0 = [&](long long uu) -> int {
     const int t = (int)(uu / kStSub), sub = (int)(uu - (long long)t * kStSub);
@@ -243,7 +247,9 @@ inline void stream_launch_pass(int mode, const unsigned char* rows, int n_rows, 
   const int grid = (int)std::max<long long>(1, std::min<long long>((long long)n_cu, (units + kStWaves - 1) / kStWaves));   // one block per CU
 #define STL_LAUNCH(MODE, NQ, NT)                                                                                                       \
   hipLaunchKernelGGL((scan_stream_lds_kernel<MODE, NQ, NT>), dim3(grid), dim3(kStThreads), st_lds_smem_bytes(NQ), st, rows, n_rows, qb16, b, \
-                     n_pass_tiles, tile_stride, skip_n, self0, thr, dense, cand_cnt, cand_s, cand_i, cap)
+                     n_pass_tiles, tile_stride, skip_n, self0, thr, dense, cand_cnt, cand_s, cand_i, cap, xcd_slices)
+  const int xcd_slices = (nt >> 1) & 1;   // nt: bit 0 = non-temporal corpus loads, bit 1 = per-XCD slices
+  nt &= 1;
   if (mode == 0) {
     if (nq == 1) STL_LAUNCH(0, 1, false); else if (nq == 2) STL_LAUNCH(0, 2, false); else STL_LAUNCH(0, 4, false);
   } else if (nt) {

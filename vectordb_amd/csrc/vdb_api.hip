@@ -118,12 +118,14 @@ struct vdb {
   int scan_blocks_per_cu = 2;    // 2 x 256 threads per CU: 96 KiB in flight per CU; 4 measured 3-4 % slower at every shard size (bf16)
   int scan_nt_loads = 1;
   int alloc_f32_first = 0;       // 1: allocate the fp32 copy before the bf16 rows (the order before round 3's placement finding)
+  int scan_xcd_slices = 1;       // unfused scan: the blocks of one XCD take adjacent tiles (0: block-by-block round-robin)
   int scan_super_rounds = 1;     // fused scan: the block groups' tiles interleave in super-rounds (one window over the corpus); 0 = a contiguous range per group
   int scan_group_launch = 1;    // GEMV batches: all whole groups of four queries in one 2-D launch (0 = one launch per group)
   int batch_mfma_min_b = 2;      // smallest batch the MFMA path may serve (the cost model decides above it)
   bool mfma_attr_set = false;    // dynamic-LDS limits of the MFMA kernels raised on this handle's device
   int mfma_cost_model = 1;       // 0: every supported batch >= batch_mfma_min_b takes the MFMA path (tests)
   int mfma_ablate = 0;   // diagnostic: skip parts of the MFMA kernel (wrong results, timing only)
+  int stream_xcd_slices = 1;   // the streaming kernel's blocks of one XCD take adjacent units (0: block-by-block round-robin)
   int stream_nt = 1;     // the streaming kernel's append passes: non-temporal corpus loads (whole lines, read once)
   // workspaces (grown on demand)
   DevBuf w_q, w_part_s, w_part_i, w_part2_s, w_part2_i, w_stage, w_out_i, w_out_d, w_idx, w_mfma;
@@ -401,7 +403,7 @@ int mfma_search(vdb_t* h, const float* qn, int b, int k, int kp, int64_t self_ro
   // 128 on large stores where the dense pass is small against the rest (profiles/r03_dense_sample_ab.txt)
   a.dense_tiles = h->mfma_dense_tiles ? h->mfma_dense_tiles : (n_rows >= 6000000 ? 128 : 64);
   a.one_pass_span = h->mfma_one_pass_span;
-  a.skip_sample = h->mfma_skip_sample; a.force_fallback = h->mfma_force_fallback; a.ablate = h->mfma_ablate; a.stream_nt = h->stream_nt;
+  a.skip_sample = h->mfma_skip_sample; a.force_fallback = h->mfma_force_fallback; a.ablate = h->mfma_ablate; a.stream_nt = h->stream_nt | (h->stream_xcd_slices << 1);
   a.qb16 = (unsigned char*)h->w_mfma.p;
   a.qb16_ready = qb16_ready;
   a.cand_s = (float*)h->w_cand_s.p; a.cand_i = (int*)h->w_cand_i.p; a.cand_cnt = (int*)h->w_cand_cnt.p;
@@ -493,7 +495,7 @@ int gemv_scan_chunk(vdb_t* h, const WsPtrs& W, const float* qn, int cb, int kk, 
     a.allow = allow;
     a.part_s = W.ps + (size_t)q * grid * kk;
     a.part_i = W.pi + (size_t)q * grid * kk;
-    a.grid = grid; a.st = st; a.ny = ny;
+    a.grid = grid; a.st = st; a.ny = ny; a.xcd_slices = h->scan_xcd_slices;
     a.smem = (size_t)4 * qb * kk * 8;   // 4 waves per scan block
     bool ok;
     const bool nt = h->scan_nt_loads != 0;
@@ -1872,9 +1874,11 @@ int vdb_set_option(vdb_t* h, const char* name, int64_t value) {
   }
   if (!strcmp(name, "scan_nt_loads")) { h->scan_nt_loads = value != 0; return VDB_OK; }
   if (!strcmp(name, "scan_group_launch")) { h->scan_group_launch = value != 0; return VDB_OK; }
+  if (!strcmp(name, "scan_xcd_slices")) { h->scan_xcd_slices = value != 0; return VDB_OK; }
   if (!strcmp(name, "scan_super_rounds")) { h->scan_super_rounds = value != 0; return VDB_OK; }
   if (!strcmp(name, "alloc_f32_first")) { h->alloc_f32_first = value != 0; return VDB_OK; }
   if (!strcmp(name, "stream_nt_loads")) { h->stream_nt = value != 0; return VDB_OK; }
+  if (!strcmp(name, "stream_xcd_slices")) { h->stream_xcd_slices = value != 0; return VDB_OK; }
   if (!strcmp(name, "mfma_ablate")) { h->mfma_ablate = (int)value; return VDB_OK; }
   if (!strcmp(name, "mfma_variant")) {
     if (value < 4 || value > 6) return fail(h, VDB_ERR_ARG, "mfma_variant must be 4, 5 or 6");
