@@ -273,7 +273,7 @@ int vdb_last_timing(vdb_t* h, float* scan_ms, float* merge_ms, double* bytes_str
  * region without synchronising between steps.  reset != 0 restarts the count. */
 int vdb_timing_stats(vdb_t* h, int64_t* n_searches, double* scan_ms_sum, double* merge_ms_sum, int reset);
 
-/* Tuning knobs: "timing_ring", "timing_every" (record the timing events on every Nth search only; default 1), "scan_blocks_per_cu", "scan_nt_loads", "scan_xcd_slices" and "stream_xcd_slices" (default 1: the blocks of one XCD take adjacent tiles of each grid-wide step; 0 = block-by-block round-robin; same results), "scan_super_rounds" (default 1: the one-launch scan's block groups take their tiles as slices of super-rounds, so the grid walks the corpus as one window; 0 = one contiguous range per group; same results), "alloc_f32_first" (default 0: a bf16 store's scanned rows are allocated before its fp32 rerank copy; set before the first reserve/add), "scan_group_launch" (default 1: a GEMV-path batch sends all its whole groups of four queries in ONE 2-D launch; 0 = one launch per group; same results), "batch_mfma_min_b" (default 2),
+/* Tuning knobs: "timing_ring", "timing_every" (record the timing events on every Nth search only; default 1), "scan_blocks_per_cu", "scan_nt_loads", "scan_xcd_slices" and "stream_xcd_slices" (default 1: the blocks of one XCD take adjacent tiles of each grid-wide step; 0 = block-by-block round-robin; same results), "scan_super_rounds" (default 1 = 8 tiles per wave and super-round; 2..64 set that number: the one-launch scan's block groups take their tiles as slices of super-rounds, so the grid walks the corpus as one window; 0 = one contiguous range per group; same results), "alloc_f32_first" (default 0: a bf16 store's scanned rows are allocated before its fp32 rerank copy; set before the first reserve/add), "scan_group_launch" (default 1: a GEMV-path batch sends all its whole groups of four queries in ONE 2-D launch; 0 = one launch per group; same results), "batch_mfma_min_b" (default 2),
  * "mfma_cost_model" (default 1: a batch takes the MFMA path only where it is faster than ceil(b/4) GEMV passes;
  * 0: whenever it is supported), "mfma_variant" (4: 256x128 tiles only; 5: + 256x256 tiles; 6, default: + the streaming
  * kernel for <= 64 queries), "stream_nt_loads", "mfma_append_cap", "mfma_split_x1000" (where the sample pass sits between the dense sample and

@@ -33,7 +33,7 @@ struct FusedScanArgs {
   unsigned* ticket;                // kFusedTicketBytes, zero before the first launch: the arrival counter (the last arriver resets it), and
                                    // on lines of their own the per-class scan-time sums and the class shares that tune themselves
   int balance;                     // != 0: deal each group of blocks (same XCD, same turn on its CU) a range of tiles by its self-tuned share
-  int super_rounds;                // != 0 (default): the groups' tiles interleave in super-rounds, one window over the corpus; 0: one contiguous range per group (round 3's first form, for A/B)
+  int super_rounds;                // > 0: the groups' tiles interleave in super-rounds of this many tiles per wave of the grid (default kFusedTilesPerWaveAndRoundC), one window over the corpus; 0: one contiguous range per group (round 3's first form, for A/B)
   int n_cu;                        // compute units of the device (blocks beyond the first n_cu are a CU's second, third, ... block)
   int rerank; const float* rows_f32; const uint16_t* rows_b16;   // fp32 copy (or nullptr: re-score against the bf16 rows)
   long long row_offset;
@@ -46,7 +46,7 @@ constexpr int kFusedMaxRounds = 4;          // block groups: 8 XCD classes x up 
 constexpr int kFusedDurOffset = 32;         // unsigneds from the ticket: [32] sums of block scan times (100 MHz ticks) per group
 constexpr int kFusedShareOffset = 64;       // [32] group shares (0 = not tuned yet = kFusedShareUnit)
 constexpr int kFusedShareUnit = 1024;
-constexpr int kFusedTilesPerWaveAndRoundC = 4;   // super-round of the fused scan's tile partition: this many tiles per wave of the grid
+constexpr int kFusedTilesPerWaveAndRoundC = 8;   // super-round of the fused scan's tile partition: this many tiles per wave of the grid
 constexpr int kFusedMaxParts = 1024;        // lists per query (= scan blocks) the fused epilogue covers
 // dim 768 or 384, qb in {1,2,4}, k' <= 64, grid <= kFusedMaxParts; false = no such instantiation
 bool launch_scan_fused(bool bf16, int dim, const FusedScanArgs& a, int qb, bool nt, int grid, hipStream_t st);

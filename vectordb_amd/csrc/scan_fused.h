@@ -30,7 +30,7 @@ namespace vdbk {
 constexpr int kFusedSurvivorCap = 2048;     // (score, index) pairs the last block keeps in LDS
 static_assert(kFusedMaxParts == 4 * kScanThreads, "the bound step holds 4 list heads per thread");
 constexpr int kFusedRerankRows = 10;        // rows a wave re-scores at a time (30 x 16 bytes in flight per lane at 768-d: k' = 40 in ONE round trip)
-constexpr int kFusedTilesPerWaveAndRound = kFusedTilesPerWaveAndRoundC;   // super-round = this many tiles per wave of the grid (512 blocks: 8192 tiles = 100 MB of 768-d bf16)
+constexpr int kFusedTilesPerWaveAndRound = kFusedTilesPerWaveAndRoundC;   // super-round = this many tiles per wave of the grid (512 blocks: 16384 tiles = 200 MB of 768-d bf16)
 constexpr int kFusedSweepAhead = 20;        // 16-byte loads per thread of one sweep round (512 lists x 40 = one round)
 
 // LDS of the last block's epilogue, behind the block merge area (see fused_smem_bytes)
@@ -183,10 +183,10 @@ __global__ __launch_bounds__(kScanThreads) void scan_topk_fused_kernel(const Fus
       if (g == grp) mine = wgt;
       total += wgt;
     }
-    // super-rounds of kFusedTilesPerWaveAndRound tiles per wave of the grid: the class owns [S_g, S_g + q) of each;
+    // super-rounds of a.super_rounds (default kFusedTilesPerWaveAndRound) tiles per wave of the grid: the class owns [S_g, S_g + q) of each;
     // what is left behind the last full one (all of a small store) is split by the same weights (TileWalk, scan_gemv.h)
-    const long long R = (long long)kFusedTilesPerWaveAndRound * n_blocks * kScanWaves;
-    const long long full = a.super_rounds ? n_tiles / R : 0, rem = n_tiles - full * R;
+    const long long R = (long long)max(1, a.super_rounds) * n_blocks * kScanWaves;
+    const long long full = a.super_rounds > 0 ? n_tiles / R : 0, rem = n_tiles - full * R;
     const long long s_lo = R * before / total, s_hi = R * (before + mine) / total;
     const long long t_lo = rem * before / total, t_hi = rem * (before + mine) / total;
     wk.wid = (((int)blockIdx.x - my_round * n_cu) >> 3) * kScanWaves + w;

@@ -119,7 +119,7 @@ struct vdb {
   int scan_nt_loads = 1;
   int alloc_f32_first = 0;       // 1: allocate the fp32 copy before the bf16 rows (the order before round 3's placement finding)
   int scan_xcd_slices = 1;       // unfused scan: the blocks of one XCD take adjacent tiles (0: block-by-block round-robin)
-  int scan_super_rounds = 1;     // fused scan: the block groups' tiles interleave in super-rounds (one window over the corpus); 0 = a contiguous range per group
+  int scan_super_rounds = kFusedTilesPerWaveAndRoundC;     // tiles per wave and super-round (0 = off); fused scan: the block groups' tiles interleave in super-rounds (one window over the corpus); 0 = a contiguous range per group
   int scan_group_launch = 1;    // GEMV batches: all whole groups of four queries in one 2-D launch (0 = one launch per group)
   int batch_mfma_min_b = 2;      // smallest batch the MFMA path may serve (the cost model decides above it)
   bool mfma_attr_set = false;    // dynamic-LDS limits of the MFMA kernels raised on this handle's device
@@ -1875,7 +1875,10 @@ int vdb_set_option(vdb_t* h, const char* name, int64_t value) {
   if (!strcmp(name, "scan_nt_loads")) { h->scan_nt_loads = value != 0; return VDB_OK; }
   if (!strcmp(name, "scan_group_launch")) { h->scan_group_launch = value != 0; return VDB_OK; }
   if (!strcmp(name, "scan_xcd_slices")) { h->scan_xcd_slices = value != 0; return VDB_OK; }
-  if (!strcmp(name, "scan_super_rounds")) { h->scan_super_rounds = value != 0; return VDB_OK; }
+  if (!strcmp(name, "scan_super_rounds")) {   // tiles per wave of the grid and super-round (1 = the default, for the on/off form; 0 = off)
+    if (value < 0 || value > 64) return fail(h, VDB_ERR_ARG, "scan_super_rounds must be in [0,64]");
+    h->scan_super_rounds = value == 1 ? kFusedTilesPerWaveAndRoundC : (int)value; return VDB_OK;
+  }
   if (!strcmp(name, "alloc_f32_first")) { h->alloc_f32_first = value != 0; return VDB_OK; }
   if (!strcmp(name, "stream_nt_loads")) { h->stream_nt = value != 0; return VDB_OK; }
   if (!strcmp(name, "stream_xcd_slices")) { h->stream_xcd_slices = value != 0; return VDB_OK; }
@@ -2031,7 +2034,7 @@ int vdb_get_stat(vdb_t* h, const char* name, int64_t* value) {
       std::vector<long long> before(n_groups + 1, 0);
       for (int g = 0; g < n_groups; ++g) before[g + 1] = before[g] + (long long)(share[g] ? share[g] : kFusedShareUnit) * group_blocks(g);
       std::vector<ProbeRange> rg((size_t)n_blocks);
-      const long long R = (long long)kFusedTilesPerWaveAndRoundC * n_blocks * 4, full = h->scan_super_rounds ? n_tiles / R : 0, rem = n_tiles - full * R, total = before[n_groups];
+      const long long R = (long long)std::max(1, h->scan_super_rounds) * n_blocks * 4, full = h->scan_super_rounds > 0 ? n_tiles / R : 0, rem = n_tiles - full * R, total = before[n_groups];
       for (int b = 0; b < n_blocks; ++b) {   // the partition of scan_topk_fused_kernel (scan_fused.h), block by block
         const int round = std::min(b / n_cu, rounds - 1), grp = (b & 7) + 8 * round;
         const long long s_lo = R * before[grp] / total, s_hi = R * before[grp + 1] / total;
