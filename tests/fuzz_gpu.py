@@ -52,6 +52,7 @@ def one_case(rng, case):
         "mfma_variant": int(rng.choice([4, 5, 6, 6])),
         "mfma_skip_sample": int(rng.integers(0, 2)),
         "stream_nt_loads": int(rng.integers(0, 2)),
+        "stream_xcd_slices": int(rng.integers(0, 2)),
         "mfma_append_cap": int(rng.choice([256, 1024, 16384, 16384])),
         "mfma_split_x1000": int(rng.choice([250, 500, 650])),
     }
@@ -112,6 +113,9 @@ def gemv_case(rng, case):
     dim = int(rng.choice([1, 2, 7, 8, 33, 64, 100, 384, 385, 768, 769, 1024, 1100]))
     n = int(rng.choice([1, 5, 63, 64, 65, 257, 1000, 4095, 4097, 9999, 30011]))
     b = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 63, 64, 65, 150]))
+    if dim in (384, 768) and rng.integers(0, 6) == 0:     # long enough for whole super-rounds of the fused scan's partition
+        n = int(rng.choice([60_001, 120_007]))
+        b = int(rng.choice([1, 2, 4, 9]))
     k = int(rng.choice([1, 3, 10, 64, 65, 200, 1024]))
     dtype = str(rng.choice(["f32", "bf16"]))
     kp = 0
@@ -130,6 +134,12 @@ def gemv_case(rng, case):
     ix = FlatIndex(dim, dtype, keep)
     try:
         ix.set_option("mfma_cost_model", int(rng.integers(0, 2)))
+        # how the scan deals its tiles and issues its launches never changes an answer
+        ix.set_option("scan_super_rounds", int(rng.choice([0, 1, 2, 8, 64])))
+        ix.set_option("scan_xcd_slices", int(rng.integers(0, 2)))
+        ix.set_option("scan_group_launch", int(rng.integers(0, 2)))
+        ix.set_option("fuse_small_batch", int(rng.choice([0, 1, 1, 2])))
+        ix.set_option("scan_blocks_per_cu", int(rng.choice([1, 2, 2, 3, 4])))
         ix.add(rows)
         if off:
             ix.set_row_offset(off)

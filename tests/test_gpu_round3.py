@@ -409,3 +409,43 @@ def test_allocation_order_is_only_a_placement(hip_lib, oracle_mod):
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
     r_idx, _, _ = oracle_mod.exact_topk(oracle_mod.normalize_rows(rows), queries, 10)
     assert np.array_equal(got[0][0][0][:, 0], r_idx[:, 0])
+
+
+@pytest.mark.parametrize("dtype,dim", [("bf16", 768), ("f32", 768), ("bf16", 384)])
+def test_super_round_partition_covers_every_tile_once(hip_lib, oracle_mod, dtype, dim):
+    """The fused scan's block groups take slices of super-rounds (TileWalk, scan_gemv.h).  Whatever the size of a round
+    and the grid — whole rounds, the split remainder, a store shorter than one round — every tile is scored exactly
+    once: same bits as one range per group (scan_super_rounds = 0), as the unfused kernels, and the oracle's answers.
+    A planted copy of the query in EVERY 997th row must come back complete: a tile left out or read twice shows."""
+    n = 70_001
+    spec = SynthSpec(seed=81, kind=1, n_clusters=263, noise=0.3)
+    rows = oracle_mod.synth_rows(0, n, dim, spec)
+    rng = np.random.default_rng(5)
+    q = rng.standard_normal((4, dim)).astype(np.float32)
+    planted = np.arange(3, n, 997)
+    rows[planted] = q[0] * 3.0                           # 71 exact copies of query 0 (up to scale), spread over the store
+    rows_n = oracle_mod.normalize_rows(rows)
+    ix = FlatIndex(dim, dtype, True)
+    ix.add(rows)
+    ix.set_option("batch_mfma_min_b", 1 << 20)
+    ix.set_option("fuse_small_batch", 2)
+    kp = 64 if dtype == "bf16" else 0
+    ref = None
+    for bpc in (2, 1, 3):
+        ix.set_option("scan_blocks_per_cu", bpc)
+        for c in (0, 2, 3, 8, 64):
+            ix.set_option("scan_super_rounds", c)
+            for rep in range(3):                          # the shares tune themselves between launches: three partitions per setting
+                got = [ix.search(q[:b], 64, kp) for b in (1, 2, 4)]
+                if ref is None:
+                    ref = got
+                for (gi, gd), (ri, rd) in zip(got, ref):
+                    assert np.array_equal(gi, ri) and np.array_equal(gd.view(np.uint32), rd.view(np.uint32)), f"{dtype} bpc={bpc} c={c} rep={rep}"
+    assert ref[0][0][0].tolist() == planted[:64].tolist()      # 71 equal scores: the 64 lowest row indices, in order
+    ix.set_option("fuse_small_batch", 0)
+    un = ix.search(q, 64, kp)
+    assert np.array_equal(un[0], ref[2][0]) and np.array_equal(un[1].view(np.uint32), ref[2][1].view(np.uint32))
+    if dtype == "f32":                                         # (bf16 candidates with k' = k have no head-room for a strict check)
+        r_idx, r_dist, r_sc = oracle_mod.exact_topk(rows_n, q, 64)
+        check_topk(un[0][1:], un[1][1:], r_idx[1:], r_dist[1:], r_sc[1:], rows_n, oracle_mod.normalize_rows(q)[1:], what=f"super rounds {dtype} {dim}")
+    ix.close()
