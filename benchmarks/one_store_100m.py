@@ -19,23 +19,32 @@ out = {"rows": n, "generated_s": round(time.perf_counter() - t0, 2)}
 ix.set_option("timing_every", 65536)
 q = torch.empty((64, dim), dtype=torch.float32, device="cuda")
 ix.synth_rows_device(q.data_ptr(), 0, 64, qspec, st)
-src = np.array([query_source_row(qspec, j) for j in range(64)])
-for b, reps in ((1, 40), (64, 10)):
+src = np.array([query_source_row(qspec, j) for j in range(1024)])
+qb = torch.empty((1024, dim), dtype=torch.float32, device="cuda")
+ix.synth_rows_device(qb.data_ptr(), 0, 1024, qspec, st)
+for b, reps in ((1, 40), (64, 10), (1024, 3)):
     oi = torch.empty((b, 10), dtype=torch.int64, device="cuda"); od = torch.empty((b, 10), dtype=torch.float32, device="cuda")
     for i in range(reps):
-        ix.search_device(q[(i % 64) if b == 1 else 0].data_ptr(), b, 10, 40, oi.data_ptr(), od.data_ptr(), st)
+        ix.search_device((qb if b > 64 else q[(i % 64) if b == 1 else 0]).data_ptr(), b, 10, 40, oi.data_ptr(), od.data_ptr(), st)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(reps):
-        ix.search_device(q[(i % 64) if b == 1 else 0].data_ptr(), b, 10, 40, oi.data_ptr(), od.data_ptr(), st)
+        ix.search_device((qb if b > 64 else q[(i % 64) if b == 1 else 0]).data_ptr(), b, 10, 40, oi.data_ptr(), od.data_ptr(), st)
     torch.cuda.synchronize()
     ms = 1e3 * (time.perf_counter() - t0) / reps
-    out[f"b{b}"] = {"ms_per_step": round(ms, 3), "GBps": round(n * dim * 2 / ms / 1e6, 1), "last_path": ix.get_stat("last_path")}
+    out[f"b{b}"] = {"ms_per_step": round(ms, 3), "GBps": round(n * dim * 2 / ms / 1e6, 1), "TFLOPs": round(2.0 * b * n * dim / ms / 1e9, 1), "qps": round(1e3 * b / ms, 1), "last_path": ix.get_stat("last_path")}
 oi = torch.empty((64, 10), dtype=torch.int64, device="cuda"); od = torch.empty((64, 10), dtype=torch.float32, device="cuda")
 ix.search_device(q.data_ptr(), 64, 10, 40, oi.data_ptr(), od.data_ptr(), st)
 torch.cuda.synchronize()
 got = oi.cpu().numpy()
-out["planted_neighbour_first_64_of_64"] = bool(np.array_equal(got[:, 0], src))
+out["planted_neighbour_first_64_of_64"] = bool(np.array_equal(got[:, 0], src[:64]))
+ob = torch.empty((1024, 10), dtype=torch.int64, device="cuda"); obd = torch.empty((1024, 10), dtype=torch.float32, device="cuda")
+ix.search_device(qb.data_ptr(), 1024, 10, 40, ob.data_ptr(), obd.data_ptr(), st)
+torch.cuda.synchronize()
+gb = ob.cpu().numpy()
+out["planted_neighbour_first_1024_of_1024"] = bool(np.array_equal(gb[:, 0], src))
+out["batch1024_equals_batch64_on_the_shared_queries"] = bool(np.array_equal(gb[:64], got))
+out["mfma_overflow_fallback"] = ix.get_stat("mfma_last_overflow")
 one = torch.empty((1, 10), dtype=torch.int64, device="cuda"); oned = torch.empty((1, 10), dtype=torch.float32, device="cuda")
 ok1 = True
 for j in range(8):
