@@ -1953,6 +1953,20 @@ int vdb_get_stat(vdb_t* h, const char* name, int64_t* value) {
     *value = flag != 0;
     return VDB_OK;
   }
+  if (!strncmp(name, "mfma_prof_xcd_", 14) && name[14] >= '0' && name[14] <= '7') {   // diagnostic (mfma_ablate=8): mean cycles per wave (waits + rest) of the blocks of one XCD in the last pass
+    *value = 0;
+    if (!h->w_dense.p) return VDB_OK;
+    int rc = set_device(h);
+    if (rc) return rc;
+    std::vector<float> pr((size_t)h->n_cu * 8 * 4);
+    HIP_TRY(h, hipDeviceSynchronize());
+    HIP_TRY(h, hipMemcpy(pr.data(), h->w_dense.p, pr.size() * 4, hipMemcpyDeviceToHost));
+    double tot = 0; size_t cnt = 0;
+    for (size_t i = 0; i < pr.size() / 4; ++i)
+      if (((i / 8) & 7) == (size_t)(name[14] - '0')) { tot += (double)pr[i * 4] + pr[i * 4 + 1] + pr[i * 4 + 2]; ++cnt; }
+    *value = cnt ? (int64_t)(tot / (double)cnt) : 0;
+    return VDB_OK;
+  }
   if (!strncmp(name, "mfma_prof_", 10) && name[10] >= 'a' && name[10] <= 'd') {   // diagnostic: mean stamp totals of mfma_ablate=8
     *value = 0;
     if (!h->w_dense.p) return VDB_OK;
